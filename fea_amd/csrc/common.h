@@ -1,0 +1,51 @@
+// Shared device/host helpers for the fea_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/fea_unet.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// Activations and packed weights are stored as "128-byte channel rows": one
+// row holds CK consecutive channels of one pixel (or of one output channel of
+// a packed weight).  16-byte chunk = EPC elements.
+template <typename T> struct Elem;
+template <> struct Elem<float>  { static constexpr int CK = 32; static constexpr int EPC = 4; static constexpr int DT = FEA_F32; };
+template <> struct Elem<__bf16> { static constexpr int CK = 64; static constexpr int EPC = 8; static constexpr int DT = FEA_BF16; };
+
+// One "k-step" = the same 16-byte chunk of an A row and a B row in every lane:
+// bf16 -> one 32x32x16 MFMA, fp32 -> four exact-f32 32x32x2 MFMAs.  A and B use
+// the same lane->k map, so any consistent k order is correct.
+__device__ __forceinline__ void mma16(f32x16& acc, const u32x4& a, const u32x4& b, const float*) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[t]), __builtin_bit_cast(float, b[t]), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x16& acc, const u32x4& a, const u32x4& b, const __bf16*) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+// XCD-aware bijective block remap (blocks b and b+8 share an XCD/L2): each XCD
+// gets a contiguous range of logical tile ids.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// host side -----------------------------------------------------------------
+void fea_set_error(const char* fmt, ...);
+#define FEA_CHECK(cond, code, ...) do { if (!(cond)) { fea_set_error(__VA_ARGS__); return (code); } } while (0)
+#define FEA_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+    fea_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return FEA_E_LAUNCH; } } while (0)

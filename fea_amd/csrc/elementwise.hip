@@ -1,0 +1,623 @@
+// Bandwidth-bound kernels: layout/packing, BatchNorm(+ReLU+MaxPool) forward and
+// backward, per-channel reductions.  All activation accesses are 16 bytes per
+// lane with the channel group as the fastest-varying index, so a wave reads
+// and writes whole contiguous pixel rows.
+#include "common.h"
+
+template <typename T> struct Vec { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T> __device__ __forceinline__ void unpack(const u32x4& v, float* f);
+template <> __device__ __forceinline__ void unpack<float>(const u32x4& v, float* f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = __builtin_bit_cast(float, v[j]);
+}
+template <> __device__ __forceinline__ void unpack<__bf16>(const u32x4& v, float* f) {
+    const bf16x8 b = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)b[j];
+}
+template <typename T> __device__ __forceinline__ u32x4 pack(const float* f);
+template <> __device__ __forceinline__ u32x4 pack<float>(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(uint32_t, f[j]);
+    return v;
+}
+template <> __device__ __forceinline__ u32x4 pack<__bf16>(const float* f) {
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (__bf16)f[j];
+    return __builtin_bit_cast(u32x4, b);
+}
+
+// The one definition of the BN+ReLU activation, shared by forward, pooling and
+// the backward mask / arg-max recomputation so that they agree bit for bit.
+__device__ __forceinline__ float bn_act(float y, float sc, float sh) { return fmaxf(__builtin_fmaf(y, sc, sh), 0.f); }
+
+#define GRID1D(n, bs) dim3((unsigned)(((n) + (bs) - 1) / (bs)))
+
+// ---------------------------------------------------------------------------
+// layout
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void im2col3x3_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int C, int H, int W, int Kpad) {
+    constexpr int V = Vec<T>::N;
+    const int gpp = Kpad / V;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * H * W * gpp;
+    if (i >= total) return;
+    const int grp = (int)(i % gpp);
+    long long pix = i / gpp;
+    const int xx = (int)(pix % W); pix /= W;
+    const int yy = (int)(pix % H);
+    const int n = (int)(pix / H);
+    float f[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int k = grp * V + j;
+        float v = 0.f;
+        if (k < 9 * C) {
+            const int tap = k / C, c = k - tap * C;
+            const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+            if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = x[(((long long)n * C + c) * H + sy) * W + sx];
+        }
+        f[j] = v;
+    }
+    *reinterpret_cast<u32x4*>(out + i * V) = pack<T>(f);
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, int ld, float* __restrict__ out, int N, int C, int H, int W) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * C * H * W;
+    if (i >= total) return;
+    const int xx = (int)(i % W);
+    const int yy = (int)((i / W) % H);
+    const int c = (int)((i / ((long long)W * H)) % C);
+    const int n = (int)(i / ((long long)W * H * C));
+    out[i] = to_f32(x[(((long long)n * H + yy) * W + xx) * ld + c]);
+}
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ out, int ld, int N, int C, int H, int W) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * C * H * W;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int xx = (int)((i / C) % W);
+    const int yy = (int)((i / ((long long)C * W)) % H);
+    const int n = (int)(i / ((long long)C * W * H));
+    out[(((long long)n * H + yy) * W + xx) * ld + c] = from_f32<T>(x[(((long long)n * C + c) * H + yy) * W + xx]);
+}
+
+// packed conv3x3 weight: out[(chunk*9+tap)][row][j]
+template <typename T>
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int dgrad) {
+    constexpr int CK = Elem<T>::CK;
+    const int rows = dgrad ? Ci : Co;          // GEMM N
+    const int kch = dgrad ? Co : Ci;           // GEMM K channels
+    const long long total = (long long)9 * rows * kch;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % CK);
+    const int row = (int)((i / CK) % rows);
+    const int kc = (int)(i / ((long long)CK * rows));
+    const int chunk = kc / 9, tap = kc - chunk * 9;
+    const int kk = chunk * CK + j;
+    float v;
+    if (!dgrad) v = w[((long long)row * Ci + kk) * 9 + tap];
+    else        v = w[((long long)kk * Ci + row) * 9 + (8 - tap)];
+    out[i] = from_f32<T>(v);
+}
+template <typename T>
+__global__ void pack_conv3x3_im2col_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int C, int Kpad) {
+    constexpr int CK = Elem<T>::CK;
+    const long long total = (long long)Co * Kpad;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    // out[chunk][co][j], k = chunk*CK + j
+    const int j = (int)(i % CK);
+    const int co = (int)((i / CK) % Co);
+    const int chunk = (int)(i / ((long long)CK * Co));
+    const int k = chunk * CK + j;
+    float v = 0.f;
+    if (k < 9 * C) { const int tap = k / C, c = k - tap * C; v = w[((long long)co * C + c) * 9 + tap]; }
+    out[i] = from_f32<T>(v);
+}
+template <typename T>
+__global__ void pack_upconv_kernel(const float* __restrict__ w, T* __restrict__ out, int Ci, int Co, int bwd) {
+    constexpr int CK = Elem<T>::CK;
+    const long long total = (long long)4 * Ci * Co;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % CK);
+    float v;
+    if (!bwd) {       // out[chunk][ab*Co+co][j] = w[chunk*CK+j][co][ab]
+        const int row = (int)((i / CK) % (4 * Co));
+        const int chunk = (int)(i / ((long long)CK * 4 * Co));
+        const int ab = row / Co, co = row - ab * Co;
+        v = w[(((long long)(chunk * CK + j)) * Co + co) * 4 + ab];
+    } else {          // out[ab*(Co/CK)+chunk][ci][j] = w[ci][chunk*CK+j][ab]
+        const int ci = (int)((i / CK) % Ci);
+        const int kc = (int)(i / ((long long)CK * Ci));
+        const int nch = Co / CK;
+        const int ab = kc / nch, chunk = kc - ab * nch;
+        v = w[((long long)ci * Co + chunk * CK + j) * 4 + ab];
+    }
+    out[i] = from_f32<T>(v);
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm statistics
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+    // 256 threads; result valid in thread 0
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// one block per channel
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int ntiles, long long count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float momentum, float eps,
+                                                          float* scale, float* shift, float* save_mean, float* save_invstd, int C) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 256) {
+        const float2 v = *reinterpret_cast<const float2*>(stats + ((long long)t * C + c) * 2);
+        s += v.x; q += v.y;
+    }
+    s = block_sum_d(s, sh);
+    q = block_sum_d(q, sh);
+    if (threadIdx.x == 0) {
+        const double mean = s / (double)count;
+        double var = q / (double)count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        save_mean[c] = (float)mean;
+        save_invstd[c] = invstd;
+        if (running_mean) {
+            const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ---------------------------------------------------------------------------
+// BN + ReLU (+ 2x2 max-pool) forward
+// ---------------------------------------------------------------------------
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, T* __restrict__ out_full, int ld_full,
+                                                           T* __restrict__ out_pool, int N, int H, int W, int C) {
+    constexpr int V = Vec<T>::N;
+    const int gpp = C / V;
+    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+    const long long total = (long long)N * Ho * Wo * gpp;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int grp = (int)(i % gpp);
+    long long pix = i / gpp;
+    const int xo = (int)(pix % Wo); pix /= Wo;
+    const int yo = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    float sc[V], sh[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sc[j] = scale[grp * V + j]; sh[j] = shift[grp * V + j]; }
+    if (!POOL) {
+        const long long p = ((long long)n * H + yo) * W + xo;
+        float f[V];
+        unpack<T>(*reinterpret_cast<const u32x4*>(y + p * C + grp * V), f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) f[j] = bn_act(f[j], sc[j], sh[j]);
+        *reinterpret_cast<u32x4*>(out_full + p * ld_full + grp * V) = pack<T>(f);
+    } else {
+        float mx[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) mx[j] = 0.f;     // activations are >= 0
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+            const long long p = ((long long)n * H + 2 * yo + (w4 >> 1)) * W + 2 * xo + (w4 & 1);
+            float f[V];
+            unpack<T>(*reinterpret_cast<const u32x4*>(y + p * C + grp * V), f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { f[j] = bn_act(f[j], sc[j], sh[j]); mx[j] = fmaxf(mx[j], f[j]); }
+            *reinterpret_cast<u32x4*>(out_full + p * ld_full + grp * V) = pack<T>(f);
+        }
+        const long long po = ((long long)n * Ho + yo) * Wo + xo;
+        *reinterpret_cast<u32x4*>(out_pool + po * C + grp * V) = pack<T>(mx);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// BN + ReLU (+ pool routing) backward
+// ---------------------------------------------------------------------------
+// Work item = (window or pixel, channel group).  Blocks are 256 threads laid out
+// as [256/gpp pixel slots][gpp channel groups] when gpp <= 256.
+template <typename T, bool POOL, bool APPLY>
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const T* __restrict__ da_full, int ld_da, const T* __restrict__ dpool,
+                                                          const T* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ save_mean,
+                                                          const float* __restrict__ save_invstd, const float* __restrict__ coef,
+                                                          T* __restrict__ dy, float* __restrict__ part,
+                                                          int N, int H, int W, int C, long long items_per_block) {
+    constexpr int V = Vec<T>::N;
+    const int gpp = C / V;                       // host guarantees gpp <= 256 and 256 % gpp == 0
+    const int slots = 256 / gpp;
+    const int grp = threadIdx.x % gpp, slot = threadIdx.x / gpp;
+    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+    const long long nitems = (long long)N * Ho * Wo;
+    const long long it0 = (long long)blockIdx.x * items_per_block;
+    const long long it1 = it0 + items_per_block < nitems ? it0 + items_per_block : nitems;
+
+    float sc[V], sh[V], mu[V], is[V], c1[V], c2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = grp * V + j;
+        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = save_mean[c]; is[j] = save_invstd[c];
+        if (APPLY) { c1[j] = coef[2 * c]; c2[j] = coef[2 * c + 1]; } else { c1[j] = 0.f; c2[j] = 0.f; }
+    }
+    float a0[V], a1[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
+
+    for (long long it = it0 + slot; it < it1; it += slots) {
+        long long t = it;
+        const int xo = (int)(t % Wo); t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        constexpr int NP = POOL ? 4 : 1;
+        float yv[NP][V], g[NP][V];
+        long long pidx[NP];
+#pragma unroll
+        for (int w4 = 0; w4 < NP; ++w4) {
+            pidx[w4] = POOL ? ((long long)n * H + 2 * yo + (w4 >> 1)) * W + 2 * xo + (w4 & 1)
+                            : ((long long)n * H + yo) * W + xo;
+            unpack<T>(*reinterpret_cast<const u32x4*>(y + pidx[w4] * C + grp * V), yv[w4]);
+            if (da_full) unpack<T>(*reinterpret_cast<const u32x4*>(da_full + pidx[w4] * ld_da + grp * V), g[w4]);
+            else {
+#pragma unroll
+                for (int j = 0; j < V; ++j) g[w4][j] = 0.f;
+            }
+        }
+        if (POOL && dpool) {
+            float dp[V];
+            unpack<T>(*reinterpret_cast<const u32x4*>(dpool + (((long long)n * Ho + yo) * Wo + xo) * C + grp * V), dp);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                // first maximum in row-major window order (MaxPool2d backward, models.py:24)
+                float best = bn_act(yv[0][j], sc[j], sh[j]);
+                int bi = 0;
+#pragma unroll
+                for (int w4 = 1; w4 < NP; ++w4) {
+                    const float a = bn_act(yv[w4][j], sc[j], sh[j]);
+                    if (a > best) { best = a; bi = w4; }
+                }
+#pragma unroll
+                for (int w4 = 0; w4 < NP; ++w4) g[w4][j] += (bi == w4) ? dp[j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int w4 = 0; w4 < NP; ++w4) {
+            float o[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float act = bn_act(yv[w4][j], sc[j], sh[j]);
+                const float gg = act > 0.f ? g[w4][j] : 0.f;
+                const float xh = (yv[w4][j] - mu[j]) * is[j];
+                if (!APPLY) { a0[j] += gg; a1[j] += gg * xh; }
+                else {
+                    const float d = sc[j] * (gg - c1[j] - xh * c2[j]);
+                    o[j] = d; a0[j] += d;
+                }
+            }
+            if (APPLY) *reinterpret_cast<u32x4*>(dy + pidx[w4] * C + grp * V) = pack<T>(o);
+        }
+    }
+    // reduce over the pixel slots of this block, fixed order
+    __shared__ float red[256 * 2 * 8];           // [slot][grp][2][V] <= 256*16 floats
+    float* mine = red + (size_t)threadIdx.x * 2 * V;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { mine[j] = a0[j]; mine[V + j] = a1[j]; }
+    __syncthreads();
+    if (threadIdx.x < gpp) {
+        float s0[V], s1[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+        for (int sl = 0; sl < slots; ++sl) {
+            const float* o = red + (size_t)(sl * gpp + threadIdx.x) * 2 * V;
+#pragma unroll
+            for (int j = 0; j < V; ++j) { s0[j] += o[j]; s1[j] += o[V + j]; }
+        }
+        float* dst = part + ((long long)blockIdx.x * C + threadIdx.x * V) * 2;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { dst[2 * j] = s0[j]; dst[2 * j + 1] = s1[j]; }
+    }
+}
+
+// one block per channel: dgamma, dbeta, coef
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, long long count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ save_invstd,
+                                                              float* dgamma, float* dbeta, float* coef, int C) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int t = threadIdx.x; t < nblk; t += 256) {
+        const float2 v = *reinterpret_cast<const float2*>(part + ((long long)t * C + c) * 2);
+        s += v.x; q += v.y;
+    }
+    s = block_sum_d(s, sh);
+    q = block_sum_d(q, sh);
+    if (threadIdx.x == 0) {
+        dbeta[c] = (float)s;
+        dgamma[c] = (float)q;
+        coef[2 * c] = (float)(s / (double)count);
+        coef[2 * c + 1] = (float)(q / (double)count);
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk, int C, int slot,
+                                                              float* __restrict__ out) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int t = threadIdx.x; t < nblk; t += 256) s += part[((long long)t * C + c) * 2 + slot];
+    s = block_sum_d(s, sh);
+    if (threadIdx.x == 0) out[c] = (float)s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, int ld, long long npix, int C,
+                                                          float* __restrict__ part, long long pix_per_block) {
+    constexpr int V = Vec<T>::N;
+    const int gpp = C / V, slots = 256 / gpp;
+    const int grp = threadIdx.x % gpp, slot = threadIdx.x / gpp;
+    const long long p0 = (long long)blockIdx.x * pix_per_block;
+    const long long p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+    float a[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) a[j] = 0.f;
+    for (long long p = p0 + slot; p < p1; p += slots) {
+        float f[V];
+        unpack<T>(*reinterpret_cast<const u32x4*>(x + p * ld + grp * V), f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) a[j] += f[j];
+    }
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[threadIdx.x * V + j] = a[j];
+    __syncthreads();
+    if (threadIdx.x < gpp) {
+        float s[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) s[j] = 0.f;
+        for (int sl = 0; sl < slots; ++sl)
+#pragma unroll
+            for (int j = 0; j < V; ++j) s[j] += red[(sl * gpp + threadIdx.x) * V + j];
+        float* dst = part + ((long long)blockIdx.x * C + threadIdx.x * V) * 2;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { dst[2 * j] = s[j]; dst[2 * j + 1] = 0.f; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host wrappers
+// ---------------------------------------------------------------------------
+#define DT_SWITCH(dtype, who, ...)                                                     \
+    if ((dtype) == FEA_BF16) { typedef __bf16 T; __VA_ARGS__; }                        \
+    else if ((dtype) == FEA_F32) { typedef float T; __VA_ARGS__; }                     \
+    else { fea_set_error("%s: bad dtype %d", who, (int)(dtype)); return FEA_E_BADARG; }
+
+static inline int velems(int dtype) { return dtype == FEA_BF16 ? 8 : 4; }
+
+extern "C" int fea_im2col3x3_nchw(const float* x, void* out, int N, int C, int H, int W, int Kpad, int dtype, void* stream) {
+    FEA_CHECK(x && out && N > 0 && C > 0 && H > 0 && W > 0, FEA_E_BADARG, "fea_im2col3x3_nchw: bad args");
+    FEA_CHECK(Kpad % 64 == 0 && Kpad >= 9 * C, FEA_E_UNSUPPORTED_SHAPE, "fea_im2col3x3_nchw: Kpad=%d for C=%d", Kpad, C);
+    const long long total = (long long)N * H * W * (Kpad / velems(dtype));
+    DT_SWITCH(dtype, "fea_im2col3x3_nchw",
+              hipLaunchKernelGGL((im2col3x3_kernel<T>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, x, (T*)out, N, C, H, W, Kpad));
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_nhwc_to_nchw_f32(const void* x, int ld, float* out, int N, int C, int H, int W, int dtype, void* stream) {
+    FEA_CHECK(x && out && N > 0 && C > 0 && H > 0 && W > 0 && ld >= C, FEA_E_BADARG, "fea_nhwc_to_nchw_f32: bad args");
+    const long long total = (long long)N * C * H * W;
+    DT_SWITCH(dtype, "fea_nhwc_to_nchw_f32",
+              hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, (const T*)x, ld, out, N, C, H, W));
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_nchw_f32_to_nhwc(const float* x, void* out, int ld, int N, int C, int H, int W, int dtype, void* stream) {
+    FEA_CHECK(x && out && N > 0 && C > 0 && H > 0 && W > 0 && ld >= C, FEA_E_BADARG, "fea_nchw_f32_to_nhwc: bad args");
+    const long long total = (long long)N * C * H * W;
+    DT_SWITCH(dtype, "fea_nchw_f32_to_nhwc",
+              hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, x, (T*)out, ld, N, C, H, W));
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_pack_conv3x3(const float* w, void* out, int Co, int Ci, int dgrad, int dtype, void* stream) {
+    const int CK = dtype == FEA_BF16 ? 64 : 32;
+    FEA_CHECK(w && out && Co > 0 && Ci > 0, FEA_E_BADARG, "fea_pack_conv3x3: bad args");
+    FEA_CHECK((dgrad ? Co : Ci) % CK == 0, FEA_E_UNSUPPORTED_SHAPE, "fea_pack_conv3x3: K channels not a multiple of %d", CK);
+    const long long total = (long long)9 * Co * Ci;
+    DT_SWITCH(dtype, "fea_pack_conv3x3",
+              hipLaunchKernelGGL((pack_conv3x3_kernel<T>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, w, (T*)out, Co, Ci, dgrad));
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_pack_conv3x3_im2col(const float* w, void* out, int Co, int C, int Kpad, int dtype, void* stream) {
+    FEA_CHECK(w && out && Co > 0 && C > 0 && Kpad % 64 == 0 && Kpad >= 9 * C, FEA_E_BADARG, "fea_pack_conv3x3_im2col: bad args");
+    const long long total = (long long)Co * Kpad;
+    DT_SWITCH(dtype, "fea_pack_conv3x3_im2col",
+              hipLaunchKernelGGL((pack_conv3x3_im2col_kernel<T>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, w, (T*)out, Co, C, Kpad));
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_pack_upconv2x2(const float* w, void* out, int Ci, int Co, int bwd, int dtype, void* stream) {
+    FEA_CHECK(w && out && Ci > 0 && Co > 0 && Ci % 64 == 0 && Co % 64 == 0, FEA_E_BADARG, "fea_pack_upconv2x2: bad args");
+    const long long total = (long long)4 * Ci * Co;
+    DT_SWITCH(dtype, "fea_pack_upconv2x2",
+              hipLaunchKernelGGL((pack_upconv_kernel<T>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, w, (T*)out, Ci, Co, bwd));
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_bn_finalize(const float* stats, int ntiles, long long count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps,
+                               float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream) {
+    FEA_CHECK(stats && gamma && beta && scale && shift && save_mean && save_invstd && ntiles > 0 && count > 0 && C > 0,
+              FEA_E_BADARG, "fea_bn_finalize: bad args");
+    FEA_CHECK((running_mean == nullptr) == (running_var == nullptr), FEA_E_BADARG, "fea_bn_finalize: running stats must both be given");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, ntiles, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd, C);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                  float* scale, float* shift, int C, void* stream) {
+    FEA_CHECK(gamma && beta && rm && rv && scale && shift && C > 0, FEA_E_BADARG, "fea_bn_eval_coeffs: bad args");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, GRID1D(C, 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, rm, rv, eps, scale, shift, C);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_bn_relu_pool(const void* y, const float* scale, const float* shift, void* out_full, int ld_full,
+                                void* out_pool, int N, int H, int W, int C, int dtype, void* stream) {
+    FEA_CHECK(y && scale && shift && out_full && N > 0 && H > 0 && W > 0 && C > 0, FEA_E_BADARG, "fea_bn_relu_pool: bad args");
+    FEA_CHECK(C % 8 == 0 && ld_full >= C && ld_full % 8 == 0, FEA_E_UNSUPPORTED_SHAPE, "fea_bn_relu_pool: C=%d ld=%d", C, ld_full);
+    FEA_CHECK(!out_pool || (H % 2 == 0 && W % 2 == 0), FEA_E_UNSUPPORTED_SHAPE, "fea_bn_relu_pool: pooling needs even H,W");
+    const int V = velems(dtype);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_pool) {
+        const long long total = (long long)N * (H / 2) * (W / 2) * (C / V);
+        DT_SWITCH(dtype, "fea_bn_relu_pool",
+                  hipLaunchKernelGGL((bn_relu_pool_kernel<T, true>), GRID1D(total, 256), dim3(256), 0, s, (const T*)y, scale, shift,
+                                     (T*)out_full, ld_full, (T*)out_pool, N, H, W, C));
+    } else {
+        const long long total = (long long)N * H * W * (C / V);
+        DT_SWITCH(dtype, "fea_bn_relu_pool",
+                  hipLaunchKernelGGL((bn_relu_pool_kernel<T, false>), GRID1D(total, 256), dim3(256), 0, s, (const T*)y, scale, shift,
+                                     (T*)out_full, ld_full, (T*)nullptr, N, H, W, C));
+    }
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+// number of blocks (= rows of `part`) used by the BN backward kernels; a pure
+// function of the shape so reduce and apply agree.
+static int red_blocks(long long nitems, int slots) {
+    long long per_iter = slots;
+    long long want = (nitems + per_iter * 8 - 1) / (per_iter * 8);   // >= 8 iterations per block
+    if (want > 2048) want = 2048;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+extern "C" int fea_bn_bwd_blocks(int N, int H, int W, int C) {
+    (void)C;
+    // upper bound valid for both dtypes and both POOL variants
+    return red_blocks((long long)N * H * W, 1);
+}
+
+static int bn_bwd_launch(bool apply, const void* da_full, int ld_da, const void* dpool, const void* y, const float* scale,
+                         const float* shift, const float* save_mean, const float* save_invstd, const float* coef, void* dy,
+                         float* part, int N, int H, int W, int C, int dtype, void* stream, const char* who) {
+    FEA_CHECK(y && scale && shift && save_mean && save_invstd && part && (da_full || dpool), FEA_E_BADARG, "%s: null pointer", who);
+    FEA_CHECK(!apply || (coef && dy), FEA_E_BADARG, "%s: null coef/dy", who);
+    const int V = velems(dtype);
+    FEA_CHECK(dtype == FEA_BF16 || dtype == FEA_F32, FEA_E_BADARG, "%s: bad dtype", who);
+    FEA_CHECK(C % V == 0 && C / V <= 256 && 256 % (C / V) == 0, FEA_E_UNSUPPORTED_SHAPE, "%s: C=%d unsupported", who, C);
+    FEA_CHECK(!da_full || (ld_da >= C && ld_da % 8 == 0), FEA_E_BADARG, "%s: ld_da=%d", who, ld_da);
+    const bool pool = dpool != nullptr;
+    FEA_CHECK(!pool || (H % 2 == 0 && W % 2 == 0), FEA_E_UNSUPPORTED_SHAPE, "%s: pooling needs even H,W", who);
+    const long long nitems = pool ? (long long)N * (H / 2) * (W / 2) : (long long)N * H * W;
+    const int slots = 256 / (C / V);
+    const int nblk = red_blocks(nitems, slots);
+    FEA_CHECK(nblk <= fea_bn_bwd_blocks(N, H, W, C), FEA_E_WORKSPACE, "%s: internal block count", who);
+    long long ipb = (nitems + nblk - 1) / nblk;
+    ipb = (ipb + slots - 1) / slots * slots;
+    hipStream_t s = (hipStream_t)stream;
+    // zero the rows of `part` that no block writes (nblk may be < the bound the caller sized for)
+    const int bound = fea_bn_bwd_blocks(N, H, W, C);
+    if (bound > nblk) {
+        hipError_t e = hipMemsetAsync(part + (long long)nblk * C * 2, 0, (size_t)(bound - nblk) * C * 2 * sizeof(float), s);
+        FEA_CHECK(e == hipSuccess, FEA_E_LAUNCH, "%s: memset failed", who);
+    }
+#define BNB(POOLV, APPLYV) hipLaunchKernelGGL((bn_relu_bwd_kernel<T, POOLV, APPLYV>), dim3(nblk), dim3(256), 0, s, (const T*)da_full, ld_da, \
+        (const T*)dpool, (const T*)y, scale, shift, save_mean, save_invstd, coef, (T*)dy, part, N, H, W, C, ipb)
+    DT_SWITCH(dtype, who,
+              if (pool) { if (apply) BNB(true, true); else BNB(true, false); }
+              else      { if (apply) BNB(false, true); else BNB(false, false); });
+#undef BNB
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_bn_relu_bwd_reduce(const void* da_full, int ld_da, const void* dpool, const void* y, const float* scale,
+                                      const float* shift, const float* save_mean, const float* save_invstd, float* part,
+                                      int N, int H, int W, int C, int dtype, void* stream) {
+    return bn_bwd_launch(false, da_full, ld_da, dpool, y, scale, shift, save_mean, save_invstd, nullptr, nullptr, part,
+                         N, H, W, C, dtype, stream, "fea_bn_relu_bwd_reduce");
+}
+extern "C" int fea_bn_relu_bwd_apply(const void* da_full, int ld_da, const void* dpool, const void* y, const float* scale,
+                                     const float* shift, const float* save_mean, const float* save_invstd, const float* coef,
+                                     void* dy, float* part, int N, int H, int W, int C, int dtype, void* stream) {
+    return bn_bwd_launch(true, da_full, ld_da, dpool, y, scale, shift, save_mean, save_invstd, coef, dy, part,
+                         N, H, W, C, dtype, stream, "fea_bn_relu_bwd_apply");
+}
+
+extern "C" int fea_bn_bwd_finalize(const float* part, int nblk, long long count, const float* gamma, const float* save_invstd,
+                                   float* dgamma, float* dbeta, float* coef, int C, void* stream) {
+    FEA_CHECK(part && gamma && save_invstd && dgamma && dbeta && coef && nblk > 0 && count > 0 && C > 0, FEA_E_BADARG,
+              "fea_bn_bwd_finalize: bad args");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, nblk, count, gamma, save_invstd,
+                       dgamma, dbeta, coef, C);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_reduce_partials(const float* part, int nblk, int C, int slot, float* out, void* stream) {
+    FEA_CHECK(part && out && nblk > 0 && C > 0 && (slot == 0 || slot == 1), FEA_E_BADARG, "fea_reduce_partials: bad args");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, nblk, C, slot, out);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_channel_sum(const void* x, int ld, long long npix, int C, float* part, int* nblk_out, int dtype, void* stream) {
+    const int V = velems(dtype);
+    FEA_CHECK(x && part && nblk_out && npix > 0 && C > 0, FEA_E_BADARG, "fea_channel_sum: bad args");
+    FEA_CHECK(C % V == 0 && C / V <= 256 && 256 % (C / V) == 0 && ld >= C && ld % 8 == 0, FEA_E_UNSUPPORTED_SHAPE,
+              "fea_channel_sum: C=%d ld=%d", C, ld);
+    const int slots = 256 / (C / V);
+    const int nblk = red_blocks(npix, slots);
+    long long ppb = (npix + nblk - 1) / nblk;
+    ppb = (ppb + slots - 1) / slots * slots;
+    DT_SWITCH(dtype, "fea_channel_sum",
+              hipLaunchKernelGGL((channel_sum_kernel<T>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const T*)x, ld, npix, C, part, ppb));
+    FEA_LAUNCH_CHECK();
+    *nblk_out = nblk;
+    return FEA_OK;
+}

@@ -1,0 +1,365 @@
+// 1x1 classification head (models.py:23,46) and the build-defined segmentation
+// loss / mask / IoU.  All bandwidth-bound.
+#include "common.h"
+
+// 8 lanes cooperate on one pixel: lane `sub` owns input channels 8*sub..8*sub+7.
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* f);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* f) {
+    const u32x4 a = *reinterpret_cast<const u32x4*>(p), b = *reinterpret_cast<const u32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[j] = __builtin_bit_cast(float, a[j]); f[4 + j] = __builtin_bit_cast(float, b[j]); }
+}
+template <> __device__ __forceinline__ void load8<__bf16>(const __bf16* p, float* f) {
+    const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)b[j];
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* f);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* f) {
+    u32x4 a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = __builtin_bit_cast(uint32_t, f[j]); b[j] = __builtin_bit_cast(uint32_t, f[4 + j]); }
+    *reinterpret_cast<u32x4*>(p) = a; *reinterpret_cast<u32x4*>(p + 4) = b;
+}
+template <> __device__ __forceinline__ void store8<__bf16>(__bf16* p, const float* f) {
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (__bf16)f[j];
+    *reinterpret_cast<u32x4*>(p) = __builtin_bit_cast(u32x4, b);
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ logits,
+                                                       long long npix, long long HW, int Ccls) {
+    __shared__ float ws[NC * 64 + NC];
+    for (int i = threadIdx.x; i < NC * 64; i += 256) ws[i] = i < Ccls * 64 ? w[i] : 0.f;
+    if (threadIdx.x < NC) ws[NC * 64 + threadIdx.x] = threadIdx.x < Ccls ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const int sub = threadIdx.x & 7;
+    const long long stride = (long long)gridDim.x * 32;
+    for (long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); p < npix; p += stride) {
+        float f[8];
+        load8<T>(a + p * lda + sub * 8, f);
+        float acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = __builtin_fmaf(f[j], ws[c * 64 + sub * 8 + j], s);
+            acc[c] = s;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            acc[c] += __shfl_xor(acc[c], 1);
+            acc[c] += __shfl_xor(acc[c], 2);
+            acc[c] += __shfl_xor(acc[c], 4);
+        }
+        const long long n = p / HW, hw = p - n * HW;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if ((c & 7) == sub && c < Ccls) logits[(n * Ccls + c) * HW + hw] = acc[c] + ws[NC * 64 + c];
+    }
+}
+
+// da = W^T dl ; partial dW / db.  part[blk][c*65 + k], k = 64 -> db.
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const T* __restrict__ a, int lda,
+                                                       const float* __restrict__ w, T* __restrict__ da, int ldda,
+                                                       float* __restrict__ part, long long npix, long long HW, int Ccls,
+                                                       long long pix_per_block) {
+    __shared__ float ws[NC * 64];
+    __shared__ float red[4][NC * 65];
+    for (int i = threadIdx.x; i < NC * 64; i += 256) ws[i] = i < Ccls * 64 ? w[i] : 0.f;
+    __syncthreads();
+    const int sub = threadIdx.x & 7;
+    float gw[NC][8], gb[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        gb[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gw[c][j] = 0.f;
+    }
+    const long long p0 = (long long)blockIdx.x * pix_per_block;
+    const long long p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+    for (long long p = p0 + (threadIdx.x >> 3); p < p1; p += 32) {
+        const long long n = p / HW, hw = p - n * HW;
+        float f[8], o[8];
+        load8<T>(a + p * lda + sub * 8, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float d = c < Ccls ? dl[(n * Ccls + c) * HW + hw] : 0.f;
+            gb[c] += d;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o[j] = __builtin_fmaf(d, ws[c * 64 + sub * 8 + j], o[j]);
+                gw[c][j] = __builtin_fmaf(d, f[j], gw[c][j]);
+            }
+        }
+        store8<T>(da + p * ldda + sub * 8, o);
+    }
+    // reduce over the 8 pixel slots of each wave (lanes with equal sub), then over the 4 waves
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = gw[c][j];
+            v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            gw[c][j] = v;
+        }
+        float v = gb[c];
+        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        gb[c] = v;
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wv][c * 65 + sub * 8 + j] = gw[c][j];
+            if (sub == 0) red[wv][c * 65 + 64] = gb[c];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Ccls * 65; i += 256)
+        part[(long long)blockIdx.x * (Ccls * 65) + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+__global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __restrict__ part, int nblk, float* dW, float* db,
+                                                                int Ccls) {
+    // one block per (c, k) entry
+    __shared__ double sh[4];
+    const int i = blockIdx.x;                 // c*65 + k
+    double s = 0.0;
+    for (int t = threadIdx.x; t < nblk; t += 256) s += part[(long long)t * (Ccls * 65) + i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = sh[0] + sh[1] + sh[2] + sh[3];
+        const int c = i / 65, k = i - c * 65;
+        if (k < 64) dW[c * 64 + k] = (float)tot; else db[c] = (float)tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// loss: per (n, c) plane, blocks over chunks of HW
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// part[blk][4]; blk = (plane * chunks + chunk); plane = n*C + c
+__global__ __launch_bounds__(256) void bce_dice_sums_kernel(const float* __restrict__ x, const uint8_t* __restrict__ t,
+                                                            float* __restrict__ part, long long HW, int chunks, long long chunk_len) {
+    const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
+    const long long b = (long long)plane * HW;
+    const long long i0 = chunk * chunk_len, i1 = i0 + chunk_len < HW ? i0 + chunk_len : HW;
+    float sb = 0.f, si = 0.f, sp = 0.f, st = 0.f;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float v = x[b + i];
+        const float tt = t[b + i] ? 1.f : 0.f;
+        // stable BCE-with-logits: max(x,0) - x*t + log1p(exp(-|x|))
+        sb += fmaxf(v, 0.f) - v * tt + log1pf(expf(-fabsf(v)));
+        const float p = 1.f / (1.f + expf(-v));
+        si += p * tt; sp += p; st += tt;
+    }
+    __shared__ float sh[4][4];
+    float vals[4] = {sb, si, sp, st};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = vals[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) part[(long long)blockIdx.x * 4 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+// sums[c][4] (double) from part; one block per class
+__global__ __launch_bounds__(256) void bce_dice_sums_finalize_kernel(const float* __restrict__ part, double* __restrict__ sums,
+                                                                     int N, int C, int chunks) {
+    __shared__ double sh[4][4];
+    const int c = blockIdx.x;
+    double a[4] = {0, 0, 0, 0};
+    const int per = N * chunks;
+    for (int i = threadIdx.x; i < per; i += 256) {
+        const int n = i / chunks, ch = i - n * chunks;
+        const float* p = part + ((long long)(n * C + c) * chunks + ch) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += p[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double v = a[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) sums[c * 4 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void bce_dice_grad_kernel(const float* __restrict__ x, const uint8_t* __restrict__ t,
+                                                            const double* __restrict__ sums, float* __restrict__ loss,
+                                                            float* __restrict__ dx, float gscale, int N, int C, long long HW) {
+    const long long total = (long long)N * C * HW;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss) {
+        double bce = 0.0, dice = 0.0;
+        for (int c = 0; c < C; ++c) {
+            bce += sums[c * 4];
+            dice += (2.0 * sums[c * 4 + 1] + 1.0) / (sums[c * 4 + 2] + sums[c * 4 + 3] + 1.0);
+        }
+        loss[0] = (float)(bce / (double)total + 1.0 - dice / C);
+    }
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total || !dx) return;
+    const int c = (int)((i / HW) % C);
+    const double I = sums[c * 4 + 1], S = sums[c * 4 + 2] + sums[c * 4 + 3];
+    const float v = x[i];
+    const float tt = t[i] ? 1.f : 0.f;
+    const float p = 1.f / (1.f + expf(-v));
+    const float inv = (float)(1.0 / (S + 1.0));
+    // d dice_c / d p = (2 t (S+1) - (2I+1)) / (S+1)^2
+    const float ddice = (2.f * tt - (float)((2.0 * I + 1.0) / (S + 1.0))) * inv;
+    const float g = (p - tt) / (float)total - ddice * p * (1.f - p) / (float)C;
+    dx[i] = g * gscale;
+}
+
+__global__ __launch_bounds__(256) void mask_iou_kernel(const float* __restrict__ x, const uint8_t* __restrict__ t,
+                                                       uint8_t* __restrict__ mask, unsigned long long* __restrict__ inter,
+                                                       unsigned long long* __restrict__ uni, long long HW, int C, int chunks,
+                                                       long long chunk_len) {
+    const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
+    const int c = plane % C;
+    const long long b = (long long)plane * HW;
+    const long long i0 = chunk * chunk_len, i1 = i0 + chunk_len < HW ? i0 + chunk_len : HW;
+    unsigned ni = 0, nu = 0;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const bool pr = x[b + i] > 0.f;
+        const bool tg = t[b + i] != 0;
+        if (mask) mask[b + i] = pr ? 1 : 0;
+        ni += (pr && tg) ? 1u : 0u;
+        nu += (pr || tg) ? 1u : 0u;
+    }
+    __shared__ unsigned sh[4][2];
+    for (int o = 32; o > 0; o >>= 1) { ni += __shfl_down(ni, o); nu += __shfl_down(nu, o); }
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = ni; sh[threadIdx.x >> 6][1] = nu; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(inter + c, (unsigned long long)(sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0]));
+        atomicAdd(uni + c, (unsigned long long)(sh[0][1] + sh[1][1] + sh[2][1] + sh[3][1]));
+    }
+}
+
+__global__ void binarise_kernel(const uint8_t* __restrict__ g, uint8_t* __restrict__ o, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = g[i] > 127 ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+static int head_blocks(long long npix) {
+    long long b = (npix + 32 * 16 - 1) / (32 * 16);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+extern "C" int fea_head_bwd_blocks(int N, int H, int W) { return head_blocks((long long)N * H * W); }
+
+extern "C" int fea_head_fwd(const void* a, int lda, const float* w, const float* bias, float* logits,
+                            int N, int H, int W, int Cin, int Ccls, int dtype, void* stream) {
+    FEA_CHECK(a && w && bias && logits && N > 0 && H > 0 && W > 0, FEA_E_BADARG, "fea_head_fwd: bad args");
+    FEA_CHECK(Cin == 64, FEA_E_UNSUPPORTED_SHAPE, "fea_head_fwd: Cin=%d (the head is Conv2d(64, classes, 1))", Cin);
+    FEA_CHECK(Ccls >= 1 && Ccls <= 16, FEA_E_UNSUPPORTED_SHAPE, "fea_head_fwd: %d classes (1..16 supported)", Ccls);
+    FEA_CHECK(lda >= 64 && lda % 8 == 0, FEA_E_BADARG, "fea_head_fwd: lda=%d", lda);
+    const long long npix = (long long)N * H * W, HW = (long long)H * W;
+    const int nblk = head_blocks(npix);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FEA_BF16) {
+        if (Ccls <= 8) hipLaunchKernelGGL((head_fwd_kernel<__bf16, 8>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, logits, npix, HW, Ccls);
+        else hipLaunchKernelGGL((head_fwd_kernel<__bf16, 16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, logits, npix, HW, Ccls);
+    } else if (dtype == FEA_F32) {
+        if (Ccls <= 8) hipLaunchKernelGGL((head_fwd_kernel<float, 8>), dim3(nblk), dim3(256), 0, s, (const float*)a, lda, w, bias, logits, npix, HW, Ccls);
+        else hipLaunchKernelGGL((head_fwd_kernel<float, 16>), dim3(nblk), dim3(256), 0, s, (const float*)a, lda, w, bias, logits, npix, HW, Ccls);
+    } else { fea_set_error("fea_head_fwd: bad dtype"); return FEA_E_BADARG; }
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_head_bwd(const float* dlogits, const void* a, int lda, const float* w, void* da, int ldda, float* part,
+                            int N, int H, int W, int Cin, int Ccls, int dtype, void* stream) {
+    FEA_CHECK(dlogits && a && w && da && part && N > 0 && H > 0 && W > 0, FEA_E_BADARG, "fea_head_bwd: bad args");
+    FEA_CHECK(Cin == 64, FEA_E_UNSUPPORTED_SHAPE, "fea_head_bwd: Cin=%d", Cin);
+    FEA_CHECK(Ccls >= 1 && Ccls <= 16, FEA_E_UNSUPPORTED_SHAPE, "fea_head_bwd: %d classes (1..16 supported)", Ccls);
+    FEA_CHECK(lda >= 64 && lda % 8 == 0 && ldda >= 64 && ldda % 8 == 0, FEA_E_BADARG, "fea_head_bwd: ld");
+    const long long npix = (long long)N * H * W, HW = (long long)H * W;
+    const int nblk = head_blocks(npix);
+    long long ppb = (npix + nblk - 1) / nblk;
+    ppb = (ppb + 31) / 32 * 32;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FEA_BF16) {
+        if (Ccls <= 8) hipLaunchKernelGGL((head_bwd_kernel<__bf16, 8>), dim3(nblk), dim3(256), 0, s, dlogits, (const __bf16*)a, lda, w, (__bf16*)da, ldda, part, npix, HW, Ccls, ppb);
+        else hipLaunchKernelGGL((head_bwd_kernel<__bf16, 16>), dim3(nblk), dim3(256), 0, s, dlogits, (const __bf16*)a, lda, w, (__bf16*)da, ldda, part, npix, HW, Ccls, ppb);
+    } else if (dtype == FEA_F32) {
+        if (Ccls <= 8) hipLaunchKernelGGL((head_bwd_kernel<float, 8>), dim3(nblk), dim3(256), 0, s, dlogits, (const float*)a, lda, w, (float*)da, ldda, part, npix, HW, Ccls, ppb);
+        else hipLaunchKernelGGL((head_bwd_kernel<float, 16>), dim3(nblk), dim3(256), 0, s, dlogits, (const float*)a, lda, w, (float*)da, ldda, part, npix, HW, Ccls, ppb);
+    } else { fea_set_error("fea_head_bwd: bad dtype"); return FEA_E_BADARG; }
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_head_bwd_finalize(const float* part, int nblk, float* dW, float* db, int Cin, int Ccls, void* stream) {
+    FEA_CHECK(part && dW && db && nblk > 0 && Cin == 64 && Ccls >= 1 && Ccls <= 16, FEA_E_BADARG, "fea_head_bwd_finalize: bad args");
+    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(Ccls * 65), dim3(256), 0, (hipStream_t)stream, part, nblk, dW, db, Ccls);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+static void loss_plan(long long HW, int& chunks, long long& chunk_len) {
+    chunk_len = 256 * 32;
+    chunks = (int)((HW + chunk_len - 1) / chunk_len);
+    if (chunks < 1) chunks = 1;
+}
+extern "C" int fea_loss_blocks(int N, int Ccls, long long HW) {
+    int chunks; long long cl; loss_plan(HW, chunks, cl);
+    return N * Ccls * chunks;
+}
+
+extern "C" int fea_bce_dice_sums(const float* logits, const uint8_t* target, double* sums, float* part,
+                                 int N, int Ccls, long long HW, void* stream) {
+    FEA_CHECK(logits && target && sums && part && N > 0 && Ccls > 0 && HW > 0, FEA_E_BADARG, "fea_bce_dice_sums: bad args");
+    int chunks; long long cl; loss_plan(HW, chunks, cl);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bce_dice_sums_kernel, dim3(N * Ccls * chunks), dim3(256), 0, s, logits, target, part, HW, chunks, cl);
+    FEA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bce_dice_sums_finalize_kernel, dim3(Ccls), dim3(256), 0, s, part, sums, N, Ccls, chunks);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_bce_dice_grad(const float* logits, const uint8_t* target, const double* sums, float* loss, float* dlogits,
+                                 float gscale, int N, int Ccls, long long HW, void* stream) {
+    FEA_CHECK(logits && target && sums && (loss || dlogits) && N > 0 && Ccls > 0 && HW > 0, FEA_E_BADARG, "fea_bce_dice_grad: bad args");
+    const long long total = (long long)N * Ccls * HW;
+    const long long nb = dlogits ? (total + 255) / 256 : 1;
+    hipLaunchKernelGGL(bce_dice_grad_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, logits, target, sums, loss, dlogits,
+                       gscale, N, Ccls, HW);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_mask_iou(const float* logits, const uint8_t* target, uint8_t* mask, long long* inter, long long* uni,
+                            int N, int Ccls, long long HW, void* stream) {
+    FEA_CHECK(logits && target && inter && uni && N > 0 && Ccls > 0 && HW > 0, FEA_E_BADARG, "fea_mask_iou: bad args");
+    int chunks; long long cl; loss_plan(HW, chunks, cl);
+    hipLaunchKernelGGL(mask_iou_kernel, dim3(N * Ccls * chunks), dim3(256), 0, (hipStream_t)stream, logits, target, mask,
+                       (unsigned long long*)inter, (unsigned long long*)uni, HW, Ccls, chunks, cl);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_binarise(const uint8_t* grey, uint8_t* out, long long n, void* stream) {
+    FEA_CHECK(grey && out && n > 0, FEA_E_BADARG, "fea_binarise: bad args");
+    hipLaunchKernelGGL(binarise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grey, out, n);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}

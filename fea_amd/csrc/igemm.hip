@@ -1,0 +1,438 @@
+// Implicit-GEMM convolution kernels (MFMA, gfx950).
+//
+// One workgroup (256 threads = 4 waves) computes a tile of 256 output pixels
+// (8x32 or 16x16 of one image) x BN output channels.  GEMM view: M = pixels,
+// N = output channels, K = taps x input channels.  A rows (pixels) and B rows
+// (output channels of the packed weight) are staged in LDS as 128-byte channel
+// rows with a 16-byte-chunk XOR swizzle, and every lane reads one 16-byte chunk
+// of an A row and of a B row per k-step (common.h: mma16).
+//
+//   MODE 0  3x3, pad 1: the (TH+2)x(TW+2) halo tile of one channel chunk is
+//           staged ONCE and reused by the nine taps (row index shifted per tap);
+//           the weight tile of each tap is double-buffered.
+//   MODE 1  1x1: A rows = the tile's pixels.
+//   MODE 2  2x2 stride-2 gather (ConvTranspose2d data gradient): A row of pixel
+//           (i,j), tap (a,b) = input pixel (2i+a, 2j+b).
+//   EPI 0   y[pixel][cout0+col] (+bias, + BatchNorm partial sums)
+//   EPI 1   pixel-shuffle store of ConvTranspose2d forward: GEMM column
+//           n = ab*Cup + co goes to pixel (2i+a, 2j+b), channel co.
+//
+// Reference layers served: nn.Conv2d(ci,co,3,padding=1) models.py:28,31 (fwd and
+// dgrad), nn.ConvTranspose2d(ci,co,2,stride=2) models.py:15-21 (fwd, bwd-data).
+#include "common.h"
+
+struct IgemmArgs {
+    const void* x; const void* w; const float* bias; void* y; float* stats;
+    long long x_img_stride, y_img_stride;   // elements per image
+    int ldx, ldy;
+    int H, W;          // tile-space dims
+    int Cin, Cout;     // per-tap GEMM K channels (multiple of CK), GEMM N (multiple of BN)
+    int Cup;           // EPI 1: channels per (a,b) quadrant
+    int tw_shift, tiles_x, tiles_y;
+    int nct;           // Cout / BN
+};
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+template <typename T, int MODE, int BN, int EPI>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
+    constexpr int CK = Elem<T>::CK, EPC = Elem<T>::EPC;
+    constexpr int MT = BN == 128 ? 4 : 2;        // 32-row M tiles per wave
+    constexpr int WM = BN == 128 ? 2 : 4;        // waves along M
+    constexpr int A_ROWS = MODE == 0 ? 352 : 256;
+    constexpr int A_PASSES = A_ROWS / 32;        // 256 threads x 16 B = 32 rows per pass
+    constexpr int A_BYTES = A_ROWS * 128;
+    constexpr int NWBUF = MODE == 0 ? 2 : 1;
+    constexpr int W_BYTES = BN * 128;
+    constexpr int W_PASSES = BN / 32;
+    constexpr int EPI_STRIDE = BN * 2 + 16;      // bf16 staging row, padded
+    constexpr int EPI_BYTES = sizeof(T) == 2 ? 256 * EPI_STRIDE : 0;
+    constexpr int STAT_BYTES = WM * BN * 2 * 4;
+    constexpr int MAIN_BYTES = A_BYTES + NWBUF * W_BYTES;
+    constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES + STAT_BYTES ? MAIN_BYTES : EPI_BYTES + STAT_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    char* const ldsA = smem;
+    char* const ldsW = smem + A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = BN == 128 ? (wave >> 1) : wave;
+    const int wn = BN == 128 ? (wave & 1) : 0;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = lid % g.nct;
+    int pt = lid / g.nct;                         // pixel tile id (also the stats slot)
+    const int ptile = pt;
+    const int tile_x = pt % g.tiles_x; pt /= g.tiles_x;
+    const int tile_y = pt % g.tiles_y;
+    const int n_img = pt / g.tiles_y;
+    const int cout0 = ct * BN;
+    const int tws = g.tw_shift, TW = 1 << tws, TH = 256 >> tws;
+    const int y0 = tile_y * TH, x0 = tile_x * TW;
+    const int H = g.H, W = g.W;
+    const int nchunks = g.Cin / CK;
+
+    const T* __restrict__ xg = (const T*)g.x + (long long)n_img * g.x_img_stride;
+    const T* __restrict__ wg = (const T*)g.w;
+
+    // ---- per-thread staging descriptors for the A tile --------------------
+    // MODE 0 stages once per nine taps, so its offsets are recomputed at each
+    // staging (saves 11 live registers); the gather modes stage every k-chunk
+    // and keep theirs.
+    const int sc = tid & 7;         // 16-byte chunk of the 128-byte row this thread moves
+    auto a_desc = [&](int i, bool& ok) -> int {
+        const int row = i * 32 + (tid >> 3);
+        int gy, gx;
+        if (MODE == 0) {
+            const int HW2 = TW + 2;
+            const int hy = (tws == 5) ? row / 34 : row / 18;
+            const int hx = row - hy * HW2;
+            gy = y0 + hy - 1; gx = x0 + hx - 1;
+            ok = (hy < TH + 2) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            return ok ? (gy * W + gx) * g.ldx + sc * EPC : 0;
+        }
+        gy = y0 + (row >> tws); gx = x0 + (row & (TW - 1));
+        ok = gy < H && gx < W;
+        if (MODE == 1) return ok ? (gy * W + gx) * g.ldx + sc * EPC : 0;
+        return ok ? ((2 * gy) * (2 * W) + 2 * gx) * g.ldx + sc * EPC : 0;
+    };
+    constexpr int NDESC = MODE == 0 ? 1 : A_PASSES;
+    int a_off[NDESC];
+    unsigned a_valid = 0;
+    if (MODE != 0) {
+#pragma unroll
+        for (int i = 0; i < NDESC; ++i) {
+            bool ok; a_off[i] = a_desc(i, ok);
+            a_valid |= (ok ? 1u : 0u) << i;
+        }
+    }
+
+    // ---- per-lane fragment row descriptors ---------------------------------
+    int a_row[MT];                  // MODE 0: halo row of tap (0,0); else tile row
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int p = wm * (MT * 32) + m * 32 + r;
+        a_row[m] = MODE == 0 ? (p >> tws) * (TW + 2) + (p & (TW - 1)) : p;
+    }
+    int b_addr[2];                  // byte address of this lane's B row (chunk XOR folded in per k-step)
+    int b_swz[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int brow = wn * 64 + nt * 32 + r;
+        b_addr[nt] = brow * 128;
+        b_swz[nt] = swz(brow);
+    }
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.f;
+
+    auto stage_A = [&](int chunk, int tap_off) {
+        // global -> registers -> LDS in batches of 4 rows to bound live registers
+        constexpr int BATCH = 4;
+#pragma unroll
+        for (int b0 = 0; b0 < A_PASSES; b0 += BATCH) {
+            u32x4 v[BATCH];
+            bool okv[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                if (b0 + i < A_PASSES) {
+                    int off;
+                    if constexpr (MODE == 0) off = a_desc(b0 + i, okv[i]);
+                    else { off = a_off[b0 + i]; okv[i] = (a_valid >> (b0 + i)) & 1; }
+                    const T* src = xg + off + (okv[i] ? tap_off : 0) + chunk * CK;
+                    v[i] = *reinterpret_cast<const u32x4*>(src);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                if (b0 + i < A_PASSES) {
+                    const int row = (b0 + i) * 32 + (tid >> 3);
+                    u32x4 z = {0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x4*>(ldsA + row * 128 + ((sc ^ swz(row)) << 4)) = okv[i] ? v[i] : z;
+                }
+            }
+        }
+    };
+    auto load_W = [&](int kc, u32x4 (&v)[W_PASSES]) {
+        const T* src = wg + ((long long)kc * g.Cout + cout0) * CK + tid * EPC;
+#pragma unroll
+        for (int j = 0; j < W_PASSES; ++j) v[j] = *reinterpret_cast<const u32x4*>(src + j * 256 * EPC);
+    };
+    auto write_W = [&](int buf, const u32x4 (&v)[W_PASSES]) {
+#pragma unroll
+        for (int j = 0; j < W_PASSES; ++j) {
+            const int row = j * 32 + (tid >> 3);
+            *reinterpret_cast<u32x4*>(ldsW + buf * W_BYTES + row * 128 + ((sc ^ swz(row)) << 4)) = v[j];
+        }
+    };
+    auto compute = [&](int row_shift, int buf) {
+        int abase[MT], aswz[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row = a_row[m] + row_shift;
+            abase[m] = row * 128;
+            aswz[m] = swz(row);
+        }
+        const char* wb = ldsW + buf * W_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + h;
+            u32x4 af[MT], bf[2];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const u32x4*>(ldsA + abase[m] + ((c ^ aswz[m]) << 4));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const u32x4*>(wb + b_addr[nt] + ((c ^ b_swz[nt]) << 4));
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) mma16(acc[m][nt], af[m], bf[nt], (const T*)nullptr);
+        }
+    };
+
+    if (MODE == 0) {
+        const int HW2 = TW + 2;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            __syncthreads();                       // previous chunk fully consumed
+            {
+                u32x4 wv[W_PASSES];
+                load_W(ch * 9, wv);
+                stage_A(ch, 0);
+                write_W(0, wv);
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                u32x4 wv[W_PASSES];
+                if (tap < 8) load_W(ch * 9 + tap + 1, wv);
+                const int dy = tap / 3, dx = tap - dy * 3;
+                compute(dy * HW2 + dx, tap & 1);
+                if (tap < 8) {
+                    write_W((tap + 1) & 1, wv);
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
+        const int ntaps = MODE == 2 ? 4 : 1;
+        const int nk = ntaps * nchunks;
+        // kc = tap * nchunks + chunk
+        for (int kc = 0; kc < nk; ++kc) {
+            const int tap = MODE == 2 ? kc / nchunks : 0;
+            const int ch = kc - tap * nchunks;
+            const int tap_off = MODE == 2 ? ((tap >> 1) * (2 * W) + (tap & 1)) * g.ldx : 0;
+            u32x4 wv[W_PASSES];
+            load_W(kc, wv);
+            __syncthreads();                       // previous k-chunk consumed
+            stage_A(ch, tap_off);
+            write_W(0, wv);
+            __syncthreads();
+            compute(0, 0);
+        }
+    }
+    __syncthreads();                               // LDS is reused by the epilogue
+
+    // ---- epilogue -----------------------------------------------------------
+    const bool full = (y0 + TH <= H) && (x0 + TW <= W);
+    float bv[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = cout0 + wn * 64 + nt * 32 + r;
+        bv[nt] = g.bias ? g.bias[EPI == 1 ? col % g.Cup : col] : 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][nt][e] += bv[nt];
+
+    if (EPI == 0 && g.stats) {
+        float* st = reinterpret_cast<float*>(smem + EPI_BYTES);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[m][nt][e];
+                    if (!full) {
+                        const int p = wm * (MT * 32) + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const bool ok = (y0 + (p >> tws) < H) && (x0 + (p & (TW - 1)) < W);
+                        v = ok ? v : 0.f;
+                    }
+                    s += v; q += v * v;
+                }
+            s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 32);
+            if (h == 0) {
+                st[(wm * BN + wn * 64 + nt * 32 + r) * 2 + 0] = s;
+                st[(wm * BN + wn * 64 + nt * 32 + r) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w_ = 0; w_ < WM; ++w_) { s += st[(w_ * BN + tid) * 2]; q += st[(w_ * BN + tid) * 2 + 1]; }
+            float* dst = g.stats + ((long long)ptile * g.Cout + cout0 + tid) * 2;
+            dst[0] = s; dst[1] = q;
+        }
+    }
+
+    // output addressing
+    T* __restrict__ yg = (T*)g.y + (long long)n_img * g.y_img_stride;
+    const int ab = EPI == 1 ? cout0 / g.Cup : 0;
+    const int c_off = EPI == 1 ? cout0 - ab * g.Cup : cout0;
+    auto out_pix = [&](int p, bool& ok) -> int {
+        const int gy = y0 + (p >> tws), gx = x0 + (p & (TW - 1));
+        ok = gy < H && gx < W;
+        return EPI == 1 ? (2 * gy + (ab >> 1)) * (2 * W) + 2 * gx + (ab & 1) : gy * W + gx;
+    };
+
+    if constexpr (sizeof(T) == 2) {
+        // stage the tile as [pixel][BN] bf16 in LDS, then store whole rows
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int p = wm * (MT * 32) + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    *reinterpret_cast<T*>(smem + p * EPI_STRIDE + (wn * 64 + nt * 32 + r) * 2) = from_f32<T>(acc[m][nt][e]);
+                }
+        __syncthreads();
+        constexpr int CPR = BN / 8;               // 16-byte chunks per row
+#pragma unroll
+        for (int i = 0; i < CPR; ++i) {
+            const int q = i * 256 + tid;
+            const int p = q / CPR, c = q - p * CPR;
+            bool ok; const int pix = out_pix(p, ok);
+            if (ok) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + p * EPI_STRIDE + c * 16);
+                *reinterpret_cast<u32x4*>(yg + (long long)pix * g.ldy + c_off + c * 8) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int p = wm * (MT * 32) + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                bool ok; const int pix = out_pix(p, ok);
+                if (ok) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        yg[(long long)pix * g.ldy + c_off + wn * 64 + nt * 32 + r] = from_f32<T>(acc[m][nt][e]);
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------
+static inline int tile_shift(int W) { return W >= 32 ? 5 : 4; }
+
+extern "C" int fea_conv_num_tiles(int N, int H, int W) {
+    const int tws = tile_shift(W), TW = 1 << tws, TH = 256 >> tws;
+    return N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+}
+
+template <typename T, int MODE, int EPI>
+static int launch_igemm(IgemmArgs& a, int N, hipStream_t s) {
+    const int tws = tile_shift(a.W), TW = 1 << tws, TH = 256 >> tws;
+    a.tw_shift = tws;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    const bool bn128 = (a.Cout % 128 == 0) && !(EPI == 1 && a.Cup % 128 != 0);
+    const int BN = bn128 ? 128 : 64;
+    a.nct = a.Cout / BN;
+    const long long nblk = (long long)N * a.tiles_x * a.tiles_y * a.nct;
+    FEA_CHECK(nblk > 0 && nblk < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "igemm: grid of %lld blocks", nblk);
+    dim3 grid((unsigned)nblk), block(256);
+    if (bn128) hipLaunchKernelGGL((igemm_kernel<T, MODE, 128, EPI>), grid, block, 0, s, a);
+    else       hipLaunchKernelGGL((igemm_kernel<T, MODE, 64, EPI>), grid, block, 0, s, a);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+template <int MODE, int EPI>
+static int igemm_dispatch(IgemmArgs& a, int N, int dtype, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FEA_BF16) return launch_igemm<__bf16, MODE, EPI>(a, N, s);
+    if (dtype == FEA_F32) return launch_igemm<float, MODE, EPI>(a, N, s);
+    fea_set_error("igemm: bad dtype %d", dtype);
+    return FEA_E_BADARG;
+}
+
+static int check_common(const char* who, const void* x, int ldx, const void* w, const void* y, int ldy,
+                        int N, int H, int W, int Cin, int Cout, int dtype) {
+    const int CK = dtype == FEA_BF16 ? 64 : 32;
+    FEA_CHECK(dtype == FEA_BF16 || dtype == FEA_F32, FEA_E_BADARG, "%s: bad dtype %d", who, dtype);
+    FEA_CHECK(x && w && y, FEA_E_BADARG, "%s: null pointer", who);
+    FEA_CHECK(N > 0 && H > 0 && W > 0, FEA_E_BADARG, "%s: bad dims N=%d H=%d W=%d", who, N, H, W);
+    FEA_CHECK(Cin > 0 && Cin % CK == 0, FEA_E_UNSUPPORTED_SHAPE, "%s: Cin=%d must be a multiple of %d", who, Cin, CK);
+    FEA_CHECK(Cout > 0 && Cout % 64 == 0, FEA_E_UNSUPPORTED_SHAPE, "%s: Cout=%d must be a multiple of 64", who, Cout);
+    FEA_CHECK(ldx >= Cin && ldx % 8 == 0 && ldy % 8 == 0, FEA_E_BADARG, "%s: ldx=%d ldy=%d", who, ldx, ldy);
+    FEA_CHECK(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)w % 16 == 0), FEA_E_BADARG,
+              "%s: pointers must be 16-byte aligned", who);
+    FEA_CHECK((long long)H * W * ldx < (1ll << 31) && (long long)4 * H * W * ldy < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE,
+              "%s: image too large for 32-bit in-image offsets", who);
+    return FEA_OK;
+}
+
+extern "C" int fea_conv3x3(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, float* stats,
+                           int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    int rc = check_common("fea_conv3x3", x, ldx, w, y, ldy, N, H, W, Cin, Cout, dtype);
+    if (rc) return rc;
+    FEA_CHECK(ldy >= Cout, FEA_E_BADARG, "fea_conv3x3: ldy=%d < Cout=%d", ldy, Cout);
+    IgemmArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats;
+    a.ldx = ldx; a.ldy = ldy; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cup = Cout;
+    a.x_img_stride = (long long)H * W * ldx; a.y_img_stride = (long long)H * W * ldy;
+    return igemm_dispatch<0, 0>(a, N, dtype, stream);
+}
+
+extern "C" int fea_conv1x1(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, float* stats,
+                           int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    int rc = check_common("fea_conv1x1", x, ldx, w, y, ldy, N, H, W, Cin, Cout, dtype);
+    if (rc) return rc;
+    FEA_CHECK(ldy >= Cout, FEA_E_BADARG, "fea_conv1x1: ldy=%d < Cout=%d", ldy, Cout);
+    IgemmArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats;
+    a.ldx = ldx; a.ldy = ldy; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cup = Cout;
+    a.x_img_stride = (long long)H * W * ldx; a.y_img_stride = (long long)H * W * ldy;
+    return igemm_dispatch<1, 0>(a, N, dtype, stream);
+}
+
+extern "C" int fea_upconv2x2_fwd(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
+                                 int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    int rc = check_common("fea_upconv2x2_fwd", x, ldx, w, y, ldy, N, H, W, Cin, Cout, dtype);
+    if (rc) return rc;
+    FEA_CHECK(ldy >= Cout, FEA_E_BADARG, "fea_upconv2x2_fwd: ldy=%d < Cout=%d", ldy, Cout);
+    IgemmArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = nullptr;
+    a.ldx = ldx; a.ldy = ldy; a.H = H; a.W = W; a.Cin = Cin; a.Cout = 4 * Cout; a.Cup = Cout;
+    a.x_img_stride = (long long)H * W * ldx; a.y_img_stride = (long long)4 * H * W * ldy;
+    return igemm_dispatch<1, 1>(a, N, dtype, stream);
+}
+
+extern "C" int fea_upconv2x2_bwd_data(const void* dy, int lddy, const void* w, void* dx, int lddx,
+                                      int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    // GEMM: K channels per tap = Cout (of the transposed conv), N = Cin
+    int rc = check_common("fea_upconv2x2_bwd_data", dy, lddy, w, dx, lddx, N, H, W, Cout, Cin, dtype);
+    if (rc) return rc;
+    FEA_CHECK(lddx >= Cin, FEA_E_BADARG, "fea_upconv2x2_bwd_data: lddx=%d < Cin=%d", lddx, Cin);
+    FEA_CHECK((long long)4 * H * W * lddy < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "fea_upconv2x2_bwd_data: image too large");
+    IgemmArgs a{};
+    a.x = dy; a.w = w; a.bias = nullptr; a.y = dx; a.stats = nullptr;
+    a.ldx = lddy; a.ldy = lddx; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin; a.Cup = Cin;
+    a.x_img_stride = (long long)4 * H * W * lddy; a.y_img_stride = (long long)H * W * lddx;
+    return igemm_dispatch<2, 0>(a, N, dtype, stream);
+}

@@ -1,0 +1,183 @@
+/* libfea_unet.so -- C ABI of the MI355X-native UNet hot path.
+ *
+ * The reference (erichou1/fea) has no FFI layer: its hot path is the
+ * nn.Module `FloorPlanSegmentationModel` (data_model/models.py:6-46) whose
+ * arithmetic is dispatched by PyTorch to ATen/cuDNN kernels.  Each entry
+ * point below replaces one of those dispatches; the citation names the
+ * reference line whose nn layer it stands for.  A Python binding (ctypes, see
+ * INTEGRATION.md and fea_amd/_lib.py) is what the reference side would add.
+ *
+ * Conventions
+ *  - every function returns 0 (FEA_OK) or a negative FEA_E_* code; the text of
+ *    the last error on the calling thread is fea_last_error().
+ *  - no function allocates, synchronises or creates streams: it validates its
+ *    arguments on the host and enqueues kernels on `stream` (a hipStream_t
+ *    passed as void*; NULL = the default stream).  The caller owns every
+ *    buffer, including workspaces, and keeps them alive until the stream work
+ *    has completed.
+ *  - `dtype` is FEA_F32 or FEA_BF16: the storage type of activations and
+ *    packed weights.  Accumulation is always fp32.  Parameters, gradients,
+ *    BatchNorm statistics and logits are always fp32.
+ *  - activations are NHWC ("channels last"); `ld*` is the distance, in
+ *    elements, between two consecutive pixels, so a tensor may be a channel
+ *    slice of a wider buffer (that is how torch.cat, models.py:42-45, is
+ *    made free).  Channel counts seen by the GEMM kernels are multiples of 64.
+ *  - a "128-byte row" holds CK consecutive channels: CK = 64 (bf16) / 32 (fp32).
+ */
+#ifndef FEA_UNET_H
+#define FEA_UNET_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FEA_OK 0
+#define FEA_E_BADARG (-1)
+#define FEA_E_UNSUPPORTED_SHAPE (-2)
+#define FEA_E_WORKSPACE (-3)
+#define FEA_E_LAUNCH (-4)
+
+#define FEA_F32 0
+#define FEA_BF16 1
+
+#define FEA_PIXEL_TILE 256 /* output pixels per workgroup of the conv kernels */
+
+int fea_version(void);
+const char* fea_last_error(void);
+
+/* ---- layout / packing ---------------------------------------------------- */
+
+/* x[N,C,H,W] fp32 (NCHW, the reference's input layout, models.py:36) ->
+ * 3x3 im2col rows out[N,H,W,Kpad] with k = tap*C + c (tap = 3*dy+dx, zero
+ * padding 1, zero fill for k >= 9*C).  Kpad is a multiple of CK.  enc1.0
+ * (models.py:10,28: Conv2d(in_channels,64,3,padding=1)) then runs as a 1x1
+ * GEMM over these rows. */
+int fea_im2col3x3_nchw(const float* x, void* out, int N, int C, int H, int W, int Kpad, int dtype, void* stream);
+
+/* NHWC (ld) -> NCHW fp32, and back; used at the module boundary and by tests. */
+int fea_nhwc_to_nchw_f32(const void* x, int ld, float* out, int N, int C, int H, int W, int dtype, void* stream);
+int fea_nchw_f32_to_nhwc(const float* x, void* out, int ld, int N, int C, int H, int W, int dtype, void* stream);
+
+/* Pack nn.Conv2d(ci,co,3,padding=1).weight [Co,Ci,3,3] fp32 (models.py:28,31)
+ * into GEMM-B rows.  forward:  out[(chunk*9+tap)][co][j] = w[co][chunk*CK+j][tap]
+ *                    dgrad:    out[(chunk*9+tap)][ci][j] = w[chunk*CK+j][ci][8-tap]
+ * (dgrad of a stride-1 pad-1 3x3 conv is the same conv with flipped taps and
+ * swapped channel roles). */
+int fea_pack_conv3x3(const float* w, void* out, int Co, int Ci, int dgrad, int dtype, void* stream);
+/* enc1.0: [Co,C,3,3] -> out[0][co][k], k = tap*C + c, zero for k >= 9C (Kpad = CK multiple). */
+int fea_pack_conv3x3_im2col(const float* w, void* out, int Co, int C, int Kpad, int dtype, void* stream);
+/* nn.ConvTranspose2d(ci,co,2,stride=2).weight [Ci,Co,2,2] (models.py:15-21):
+ * forward:  out[chunk][ab*Co+co][j] = w[chunk*CK+j][co][a][b]     (GEMM N = 4*Co)
+ * bwd-data: out[ab*(Co/CK)+chunk][ci][j] = w[ci][chunk*CK+j][a][b] (GEMM N = Ci)  */
+int fea_pack_upconv2x2(const float* w, void* out, int Ci, int Co, int bwd, int dtype, void* stream);
+
+/* ---- implicit-GEMM convolutions (MFMA) ----------------------------------- */
+
+/* y = conv3x3(x, w_packed) + bias          models.py:28,31 (forward) and the
+ * data gradient of the same layers (autograd of train_direct.py:104) when
+ * called with dgrad-packed weights and bias = NULL.
+ * stats (nullable): per-workgroup partial BatchNorm sums, fp32
+ * [fea_conv_num_tiles(N,H,W)][Cout][2] = (sum y, sum y^2) over the tile's
+ * valid pixels, taken from the fp32 accumulators (models.py:29,32 train mode). */
+int fea_conv3x3(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                float* stats, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* 1x1 GEMM over pixel rows (enc1.0 on im2col rows); same epilogue as above. */
+int fea_conv1x1(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                float* stats, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+int fea_conv_num_tiles(int N, int H, int W);
+
+/* y[n,2i+a,2j+b,co] = bias[co] + sum_ci x[n,i,j,ci] w[ci,co,a,b]   models.py:15-21,42-45.
+ * (H,W) are the INPUT dims; y is [N,2H,2W] with pixel stride ldy, so it can be
+ * the first Cout channels of the concat buffer. */
+int fea_upconv2x2_fwd(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                      int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* dx[n,i,j,ci] = sum_{a,b,co} dy[n,2i+a,2j+b,co] w[ci,co,a,b]; (H,W) = dx dims. */
+int fea_upconv2x2_bwd_data(const void* dy, int lddy, const void* w_packed, void* dx, int lddx,
+                           int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+
+/* ---- weight gradients (MFMA, split over pixels, deterministic) ----------- */
+
+/* conv3x3: dW[co,ci,3,3] += sum_p dy[p,co] x[p+tap,ci] ; dW is fp32 OIHW and
+ * is OVERWRITTEN.  ws: fp32 workspace of fea_wgrad_ws_bytes() bytes.
+ * mode 0 = conv3x3, 1 = im2col/1x1 (dW[co, C, 3,3] from k = tap*C+c; Cin=Kpad, Creal=C),
+ * mode 2 = ConvTranspose2d 2x2/s2 (rows m = ci of x, cols n = co of dy, dW[ci,co,2,2]). */
+size_t fea_wgrad_ws_bytes(int mode, int N, int H, int W, int Cm, int Cn, int dtype);
+int fea_conv3x3_wgrad(const void* dy, int lddy, const void* x, int ldx, float* dW, void* ws, size_t ws_bytes,
+                      int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+int fea_conv1x1_im2col_wgrad(const void* dy, int lddy, const void* xcol, int ldx, float* dW, void* ws, size_t ws_bytes,
+                             int N, int H, int W, int Kpad, int Creal, int Cout, int dtype, void* stream);
+/* (H,W) = dims of x (low res); dy is [N,2H,2W]. */
+int fea_upconv2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dW, void* ws, size_t ws_bytes,
+                        int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+
+/* ---- BatchNorm + ReLU + MaxPool (bandwidth-bound) ------------------------- */
+
+/* Reduce the conv kernels' partial sums (fp64 accumulate) and produce, per
+ * channel: scale = gamma*invstd, shift = beta - mean*scale, save_mean,
+ * save_invstd; update running_mean/var (momentum, UNBIASED var) when
+ * running_* != NULL.                         nn.BatchNorm2d, models.py:29,32 */
+int fea_bn_finalize(const float* stats, int ntiles, long long count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps,
+                    float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream);
+/* eval mode: scale/shift from running stats. */
+int fea_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, float* scale, float* shift, int C, void* stream);
+/* a = relu(y*scale + shift) -> out_full (pixel stride ld_full; may be the skip
+ * half of a concat buffer) and, when out_pool != NULL, maxpool2x2(a) -> dense
+ * [N,H/2,W/2,C].                       models.py:29-30,32-33 and :24,38-41 */
+int fea_bn_relu_pool(const void* y, const float* scale, const float* shift, void* out_full, int ld_full,
+                     void* out_pool, int N, int H, int W, int C, int dtype, void* stream);
+/* Backward of conv->BN(train)->ReLU(->pool) for one layer.
+ *   g = (da_full ? da_full : 0) + route(dpool)   with route = max-pool backward
+ *       (first max in row-major window order, recomputed from y) ; g *= (a > 0)
+ *   pass 1: partial sums (sum g, sum g*xhat) -> part[nblk][C][2]
+ *   finalize: dgamma, dbeta, and the per-channel coefficients c1,c2
+ *   pass 2: dy = scale*(g - c1 - xhat*c2) -> dy (dense, C channels) and partial
+ *           sums of dy (conv bias gradient) -> part[nblk][C][2] slot 0.
+ * fea_bn_bwd_blocks() gives nblk for sizing `part` (fp32 [nblk][C][2]). */
+int fea_bn_bwd_blocks(int N, int H, int W, int C);
+int fea_bn_relu_bwd_reduce(const void* da_full, int ld_da, const void* dpool, const void* y,
+                           const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
+                           float* part, int N, int H, int W, int C, int dtype, void* stream);
+int fea_bn_bwd_finalize(const float* part, int nblk, long long count, const float* gamma, const float* save_invstd,
+                        float* dgamma, float* dbeta, float* coef /*[C][2]*/, int C, void* stream);
+int fea_bn_relu_bwd_apply(const void* da_full, int ld_da, const void* dpool, const void* y,
+                          const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
+                          const float* coef, void* dy, float* part, int N, int H, int W, int C, int dtype, void* stream);
+/* sum over blocks of slot `slot` of part[nblk][C][2] -> out[C] (conv/upconv bias gradients). */
+int fea_reduce_partials(const float* part, int nblk, int C, int slot, float* out, void* stream);
+/* per-channel sum over all pixels of a [npix, C] (ld) tensor -> part[nblk][C][2] slot 0
+ * (ConvTranspose2d bias gradient). */
+int fea_channel_sum(const void* x, int ld, long long npix, int C, float* part, int* nblk_out, int dtype, void* stream);
+
+/* ---- 1x1 head (models.py:23,46) -------------------------------------------- */
+/* logits[N,Ccls,H,W] fp32 NCHW = out.weight[Ccls,64] . a[N,H,W,64] + bias */
+int fea_head_fwd(const void* a, int lda, const float* w, const float* bias, float* logits,
+                 int N, int H, int W, int Cin, int Ccls, int dtype, void* stream);
+/* da[N,H,W,64] = W^T dlogits ; part[nblk][Ccls*(Cin+1)] partial sums of dW (and db in the
+ * last column); nblk = fea_head_bwd_blocks(). */
+int fea_head_bwd_blocks(int N, int H, int W);
+int fea_head_bwd(const float* dlogits, const void* a, int lda, const float* w, void* da, int ldda,
+                 float* part, int N, int H, int W, int Cin, int Ccls, int dtype, void* stream);
+int fea_head_bwd_finalize(const float* part, int nblk, float* dW, float* db, int Cin, int Ccls, void* stream);
+
+/* ---- loss / mask / IoU (not in the reference) -------- */
+/* sums[Ccls][4] (fp64) = (sum bce, sum p*t, sum p, sum t) per class over N,H,W. */
+int fea_bce_dice_sums(const float* logits, const uint8_t* target, double* sums, float* part,
+                      int N, int Ccls, long long HW, void* stream);
+int fea_loss_blocks(int N, int Ccls, long long HW);
+/* loss[0] = BCE(mean) + 1 - mean_c dice_c ; dlogits = d loss / d logits * gscale */
+int fea_bce_dice_grad(const float* logits, const uint8_t* target, const double* sums, float* loss, float* dlogits,
+                      float gscale, int N, int Ccls, long long HW, void* stream);
+/* mask = logits > 0 (nullable out); inter/union int64[Ccls] are ACCUMULATED (caller zeroes). */
+int fea_mask_iou(const float* logits, const uint8_t* target, uint8_t* mask, long long* inter, long long* uni,
+                 int N, int Ccls, long long HW, void* stream);
+/* target = grey > 127 */
+int fea_binarise(const uint8_t* grey, uint8_t* out, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
