@@ -1,0 +1,116 @@
+"""ctypes binding of libfea_unet.so (the C ABI declared in include/fea_unet.h).
+
+The library is built in-tree by `fea_amd/csrc/Makefile` (see
+`__graft_entry__.build`).  There is NO fallback: if the shared object is missing
+or a call fails, an exception is raised -- the product path never computes on
+the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+import torch
+
+F32, BF16 = 0, 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfea_unet.so")
+
+P, I, L, F, Z = c_void_p, c_int, c_longlong, c_float, c_size_t
+
+# name -> (restype, argtypes); mirrors include/fea_unet.h one to one.
+SIGNATURES = {
+    "fea_version": (I, []),
+    "fea_last_error": (c_char_p, []),
+    "fea_im2col3x3_nchw": (I, [P, P, I, I, I, I, I, I, P]),
+    "fea_nhwc_to_nchw_f32": (I, [P, I, P, I, I, I, I, I, P]),
+    "fea_nchw_f32_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),
+    "fea_pack_conv3x3": (I, [P, P, I, I, I, I, P]),
+    "fea_pack_conv3x3_im2col": (I, [P, P, I, I, I, I, P]),
+    "fea_pack_upconv2x2": (I, [P, P, I, I, I, I, P]),
+    "fea_conv3x3": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
+    "fea_conv1x1": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
+    "fea_conv_num_tiles": (I, [I, I, I]),
+    "fea_upconv2x2_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
+    "fea_upconv2x2_bwd_data": (I, [P, I, P, P, I, I, I, I, I, I, I, P]),
+    "fea_wgrad_ws_bytes": (Z, [I, I, I, I, I, I, I]),
+    "fea_conv3x3_wgrad": (I, [P, I, P, I, P, P, Z, I, I, I, I, I, I, P]),
+    "fea_conv1x1_im2col_wgrad": (I, [P, I, P, I, P, P, Z, I, I, I, I, I, I, I, P]),
+    "fea_upconv2x2_wgrad": (I, [P, I, P, I, P, P, Z, I, I, I, I, I, I, P]),
+    "fea_bn_finalize": (I, [P, I, L, P, P, P, P, F, F, P, P, P, P, I, P]),
+    "fea_bn_eval_coeffs": (I, [P, P, P, P, F, P, P, I, P]),
+    "fea_bn_relu_pool": (I, [P, P, P, P, I, P, I, I, I, I, I, P]),
+    "fea_bn_bwd_blocks": (I, [I, I, I, I]),
+    "fea_bn_relu_bwd_reduce": (I, [P, I, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "fea_bn_bwd_finalize": (I, [P, I, L, P, P, P, P, P, I, P]),
+    "fea_bn_relu_bwd_apply": (I, [P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "fea_reduce_partials": (I, [P, I, I, I, P, P]),
+    "fea_channel_sum": (I, [P, I, L, I, P, P, I, P]),
+    "fea_head_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
+    "fea_head_bwd_blocks": (I, [I, I, I]),
+    "fea_head_bwd": (I, [P, P, I, P, P, I, P, I, I, I, I, I, I, P]),
+    "fea_head_bwd_finalize": (I, [P, I, P, P, I, I, P]),
+    "fea_bce_dice_sums": (I, [P, P, P, P, I, I, L, P]),
+    "fea_loss_blocks": (I, [I, I, L]),
+    "fea_bce_dice_grad": (I, [P, P, P, P, P, F, I, I, L, P]),
+    "fea_mask_iou": (I, [P, P, P, P, P, I, I, L, P]),
+    "fea_binarise": (I, [P, P, L, P]),
+}
+
+_lib = None
+
+
+class FeaError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (once).  Raises FeaError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FeaError(
+            f"{LIB_PATH} not found: build it with `make -C fea_amd/csrc` (or `python -c 'import "
+            "__graft_entry__ as g; g.build()'`).  fea_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.bfloat16:
+        return BF16
+    if dtype == torch.float32:
+        return F32
+    raise FeaError(f"unsupported compute dtype {dtype}")
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point; tensors become raw pointers; a
+    negative status raises FeaError carrying fea_last_error()."""
+    lib = load()
+    fn = getattr(lib, name)
+    conv = [ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a for a in args]
+    rc = fn(*conv)
+    if SIGNATURES[name][0] is I and rc < 0 and not name.endswith(("_blocks", "_tiles")):
+        raise FeaError(f"{name} failed ({rc}): {lib.fea_last_error().decode()}")
+    return rc

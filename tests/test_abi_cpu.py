@@ -1,0 +1,47 @@
+"""The C-ABI library loads without a GPU and exports every symbol that
+include/fea_unet.h declares; the ctypes table mirrors the header."""
+import os
+import re
+
+import pytest
+
+from fea_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "fea_unet.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(fea_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args == "void" else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(L.LIB_PATH):
+        pytest.fail(f"{L.LIB_PATH} is not built (run __graft_entry__.build())")
+    lib = L.load()
+    decl = header_functions()
+    assert len(decl) >= 30
+    for name in decl:
+        assert hasattr(lib, name), name
+    assert lib.fea_version() >= 100
+
+
+def test_ctypes_table_matches_header():
+    decl = header_functions()
+    assert set(decl) == set(L.SIGNATURES), set(decl) ^ set(L.SIGNATURES)
+    for name, nargs in decl.items():
+        assert len(L.SIGNATURES[name][1]) == nargs, name
+
+
+def test_no_cpu_fallback_in_product():
+    """Nothing under fea_amd/ may import the oracle."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fea_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no CPU fallback", ""), os.path.join(dirpath, f)

@@ -1,0 +1,352 @@
+"""Kernel-level parity: every C-ABI compute entry point against a plain PyTorch
+fp32 CPU evaluation of the same reference layer (nn.Conv2d / BatchNorm2d /
+MaxPool2d / ConvTranspose2d semantics, models.py:15-34) on the same inputs.
+
+Tolerances (stated, per north_star): fp32 path <= 1e-4 relative (we assert
+1e-5 L2 / 1e-4 peak); bf16 path: inputs are rounded to bf16 on BOTH sides, so
+the difference is the kernel's output rounding (2^-9) and fp32 accumulation
+order -> 4e-3 L2-relative, 2e-2 peak-relative.
+"""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fea_amd import _lib as L
+from tests.helpers import max_rel, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return (1e-5, 1e-4) if dt == torch.float32 else (4e-3, 2e-2)
+
+
+def check(got, ref, dt, what="", scale=1.0):
+    l2, pk = tol(dt)
+    e2, ep = rel_l2(got.float().cpu(), ref), max_rel(got.float().cpu(), ref)
+    assert e2 < l2 * scale and ep < pk * scale, f"{what}: rel_l2={e2:.3e} peak={ep:.3e} ({dt})"
+
+
+def rnd(dt, *shape, gen):
+    """Random tensor representable in dt (so both sides see identical inputs)."""
+    return torch.randn(*shape, generator=gen).to(dt).float()
+
+
+def to_nhwc(x, dt, ld=None, off=0):
+    """NCHW fp32 CPU -> device NHWC tensor of dtype dt; optionally embedded at
+    channel offset `off` of a wider (ld) buffer filled with NaN canaries."""
+    n, c, h, w = x.shape
+    ld = ld or c
+    buf = torch.full((n, h, w, ld), float("nan"), dtype=dt, device=DEV)
+    buf[..., off:off + c] = x.permute(0, 2, 3, 1).to(dt).to(DEV)
+    return buf
+
+
+def view_ptr(buf, off):
+    return buf.data_ptr() + off * buf.element_size()
+
+
+def from_nhwc(buf, c, off=0):
+    return buf[..., off:off + c].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def S():
+    return L.stream_ptr()
+
+
+SHAPES_3X3 = [  # N, H, W, Cin, Cout
+    (2, 32, 32, 64, 64),
+    (1, 16, 16, 128, 128),      # TW = 16 tiles
+    (1, 24, 40, 64, 128),       # partial tiles in both directions
+    (1, 8, 8, 192, 64),         # tile larger than the image
+    (3, 16, 64, 64, 192),       # BN = 64 path with several cout tiles
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", SHAPES_3X3)
+def test_conv3x3_fwd_stats_and_dgrad(dt, shape):
+    n, h, w, ci, co = shape
+    g = torch.Generator().manual_seed(1)
+    x = rnd(dt, n, ci, h, w, gen=g)
+    wt = rnd(dt, co, ci, 3, 3, gen=g) / (3 * ci ** 0.5)
+    wt = wt.to(dt).float()
+    bias = torch.randn(co, generator=g)
+    ref = F.conv2d(x, wt, bias, padding=1)
+
+    xd = to_nhwc(x, dt)
+    wp = torch.empty(9 * co * ci, dtype=dt, device=DEV)
+    L.call("fea_pack_conv3x3", wt.to(DEV), wp, co, ci, 0, L.dt_code(dt), S())
+    ldy, off = co + 64, 64                      # write into a channel slice
+    y = torch.full((n, h, w, ldy), float("nan"), dtype=dt, device=DEV)
+    ntiles = L.call("fea_conv_num_tiles", n, h, w)
+    stats = torch.full((ntiles, co, 2), float("nan"), device=DEV)
+    L.call("fea_conv3x3", xd, ci, wp, bias.to(DEV), view_ptr(y, off), ldy, stats, n, h, w, ci, co, L.dt_code(dt), S())
+    torch.cuda.synchronize()
+    check(from_nhwc(y, co, off), ref, dt, "conv3x3 fwd")
+    assert torch.isnan(y[..., :off].float()).all(), "wrote outside its channel slice"
+    s = stats.double().sum(0).cpu()
+    ref_s = torch.stack([ref.double().sum((0, 2, 3)), (ref.double() ** 2).sum((0, 2, 3))], 1)
+    assert rel_l2(s, ref_s) < 1e-5, "BN partial sums"
+
+    # dgrad: same kernel, dgrad-packed weights, no bias
+    dy = rnd(dt, n, co, h, w, gen=g)
+    ref_dx = F.conv_transpose2d(dy, wt, padding=1)
+    wpd = torch.empty(9 * co * ci, dtype=dt, device=DEV)
+    L.call("fea_pack_conv3x3", wt.to(DEV), wpd, co, ci, 1, L.dt_code(dt), S())
+    dx = torch.full((n, h, w, ci), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_conv3x3", to_nhwc(dy, dt), co, wpd, None, dx, ci, None, n, h, w, co, ci, L.dt_code(dt), S())
+    torch.cuda.synchronize()
+    check(from_nhwc(dx, ci), ref_dx, dt, "conv3x3 dgrad")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64), (1, 16, 16, 128, 64), (1, 24, 40, 64, 128), (1, 8, 8, 64, 192)])
+def test_conv3x3_wgrad(dt, shape):
+    n, h, w, ci, co = shape
+    g = torch.Generator().manual_seed(2)
+    x = rnd(dt, n, ci, h, w, gen=g)
+    dy = rnd(dt, n, co, h, w, gen=g)
+    xr = x.clone().requires_grad_(False)
+    wt = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    F.conv2d(xr, wt, padding=1).backward(dy)
+    ref = wt.grad
+    code = L.dt_code(dt)
+    nbytes = L.load().fea_wgrad_ws_bytes(0, n, h, w, co, ci, code)
+    ws = torch.empty(nbytes // 4, device=DEV)
+    dW = torch.full((co, ci, 3, 3), float("nan"), device=DEV)
+    # inputs live in channel slices of wider buffers
+    xd, dyd = to_nhwc(x, dt, ld=ci + 64, off=64), to_nhwc(dy, dt, ld=co + 128, off=128)
+    L.call("fea_conv3x3_wgrad", view_ptr(dyd, 128), co + 128, view_ptr(xd, 64), ci + 64, dW, ws, nbytes,
+           n, h, w, ci, co, code, S())
+    torch.cuda.synchronize()
+    check(dW, ref, dt, "conv3x3 wgrad", scale=0.5 if dt == torch.bfloat16 else 1.0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cin", [3, 1, 5])
+def test_enc1_im2col_path(dt, cin):
+    """enc1.0 = Conv2d(in_channels, 64, 3, padding=1) as im2col rows + 1x1 GEMM."""
+    n, h, w, co, kpad = 2, 32, 48, 64, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(co, cin, 3, 3, generator=g) / 5
+    bias = torch.randn(co, generator=g)
+    code = L.dt_code(dt)
+    xcol = torch.full((n, h, w, kpad), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_im2col3x3_nchw", x.to(DEV), xcol, n, cin, h, w, kpad, code, S())
+    wp = torch.empty(co * kpad, dtype=dt, device=DEV)
+    L.call("fea_pack_conv3x3_im2col", wt.to(DEV), wp, co, cin, kpad, code, S())
+    y = torch.empty((n, h, w, co), dtype=dt, device=DEV)
+    ntiles = L.call("fea_conv_num_tiles", n, h, w)
+    stats = torch.empty((ntiles, co, 2), device=DEV)
+    L.call("fea_conv1x1", xcol, kpad, wp, bias.to(DEV), y, co, stats, n, h, w, kpad, co, code, S())
+    torch.cuda.synchronize()
+    xq, wq = x.to(dt).float(), wt.to(dt).float()
+    ref = F.conv2d(xq, wq, bias, padding=1)
+    check(from_nhwc(y, co), ref, dt, "enc1.0 fwd")
+    # weight gradient through the same rows
+    dy = rnd(dt, n, co, h, w, gen=g)
+    wz = torch.zeros(co, cin, 3, 3, requires_grad=True)
+    F.conv2d(xq, wz, padding=1).backward(dy)
+    nbytes = L.load().fea_wgrad_ws_bytes(1, n, h, w, co, kpad, code)
+    ws = torch.empty(nbytes // 4, device=DEV)
+    dW = torch.full((co, cin, 3, 3), float("nan"), device=DEV)
+    L.call("fea_conv1x1_im2col_wgrad", to_nhwc(dy, dt), co, xcol, kpad, dW, ws, nbytes, n, h, w, kpad, cin, co, code, S())
+    torch.cuda.synchronize()
+    check(dW, wz.grad, dt, "enc1.0 wgrad")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 128, 64), (1, 8, 24, 256, 128), (1, 2, 2, 1024, 512), (2, 32, 32, 64, 64)])
+def test_upconv2x2(dt, shape):
+    """ConvTranspose2d(ci, co, 2, stride=2): forward into the concat buffer, data
+    gradient, weight gradient, bias gradient."""
+    n, h, w, ci, co = shape
+    g = torch.Generator().manual_seed(4)
+    code = L.dt_code(dt)
+    x = rnd(dt, n, ci, h, w, gen=g)
+    wt = (torch.randn(ci, co, 2, 2, generator=g) / ci ** 0.5).to(dt).float()
+    bias = torch.randn(co, generator=g)
+    ref = F.conv_transpose2d(x, wt, bias, stride=2)
+    wp = torch.empty(4 * ci * co, dtype=dt, device=DEV)
+    L.call("fea_pack_upconv2x2", wt.to(DEV), wp, ci, co, 0, code, S())
+    cat = torch.full((n, 2 * h, 2 * w, 2 * co), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_upconv2x2_fwd", to_nhwc(x, dt), ci, wp, bias.to(DEV), cat, 2 * co, n, h, w, ci, co, code, S())
+    torch.cuda.synchronize()
+    check(from_nhwc(cat, co, 0), ref, dt, "upconv fwd")
+    assert torch.isnan(cat[..., co:].float()).all(), "skip half of the concat buffer was touched"
+
+    dy = rnd(dt, n, co, 2 * h, 2 * w, gen=g)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    F.conv_transpose2d(xr, wr, br, stride=2).backward(dy)
+    dyd = to_nhwc(dy, dt, ld=2 * co, off=0)     # gradient of the concat buffer's first half
+    wpb = torch.empty(4 * ci * co, dtype=dt, device=DEV)
+    L.call("fea_pack_upconv2x2", wt.to(DEV), wpb, ci, co, 1, code, S())
+    dx = torch.full((n, h, w, ci), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_upconv2x2_bwd_data", dyd, 2 * co, wpb, dx, ci, n, h, w, ci, co, code, S())
+    nbytes = L.load().fea_wgrad_ws_bytes(2, n, h, w, ci, co, code)
+    ws = torch.empty(nbytes // 4, device=DEV)
+    dW = torch.full((ci, co, 2, 2), float("nan"), device=DEV)
+    L.call("fea_upconv2x2_wgrad", to_nhwc(x, dt), ci, dyd, 2 * co, dW, ws, nbytes, n, h, w, ci, co, code, S())
+    part = torch.empty((2048, co, 2), device=DEV)
+    nb = ctypes.c_int(0)
+    L.call("fea_channel_sum", dyd, 2 * co, n * 4 * h * w, co, part, ctypes.byref(nb), code, S())
+    db = torch.empty(co, device=DEV)
+    L.call("fea_reduce_partials", part, nb.value, co, 0, db, S())
+    torch.cuda.synchronize()
+    check(from_nhwc(dx, ci), xr.grad, dt, "upconv bwd data")
+    check(dW, wr.grad, dt, "upconv wgrad")
+    assert rel_l2(db.cpu(), br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 16, 32, 64, True), (1, 8, 8, 1024, False), (3, 32, 32, 128, True), (1, 2, 2, 256, False)])
+def test_bn_relu_pool_forward_backward(dt, shape):
+    """conv output -> BatchNorm2d(train) -> ReLU (-> MaxPool2d(2)) and its
+    backward, against autograd on the same ops.  The conv output is kept away
+    from the ReLU kink and from pool ties so the comparison is smooth."""
+    n, h, w, c, pool = shape
+    g = torch.Generator().manual_seed(5)
+    code = L.dt_code(dt)
+    y = rnd(dt, n, c, h, w, gen=g) * 2 + 0.3
+    gamma = torch.rand(c, generator=g) + 0.5
+    gamma[::7] *= -1                                   # negative gamma must work too
+    beta = torch.randn(c, generator=g) * 0.2
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    bn = F.batch_norm(yr, rm_ref, rv_ref, gr, br, training=True, momentum=0.1, eps=1e-5)
+    # keep |bn| away from 0 where the two sides could disagree on the mask
+    keep = bn.detach().abs() > 2e-2
+    a = torch.relu(bn)
+    outs = [a]
+    if pool:
+        outs.append(F.max_pool2d(a, 2))
+
+    # device side: partial stats as the conv epilogue would have produced them (one "tile")
+    yd = to_nhwc(y, dt)
+    stats = torch.stack([y.double().sum((0, 2, 3)), (y.double() ** 2).sum((0, 2, 3))], 1).float().to(DEV).reshape(1, c, 2).contiguous()
+    scale, shift, smean, sinv = (torch.empty(c, device=DEV) for _ in range(4))
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    L.call("fea_bn_finalize", stats, 1, n * h * w, gamma.to(DEV), beta.to(DEV), rmd, rvd, 0.1, 1e-5, scale, shift, smean, sinv, c, S())
+    ld = 2 * c
+    full = torch.full((n, h, w, ld), float("nan"), dtype=dt, device=DEV)
+    pooled = torch.full((n, h // 2, w // 2, c), float("nan"), dtype=dt, device=DEV) if pool else None
+    L.call("fea_bn_relu_pool", yd, scale, shift, view_ptr(full, c), ld, pooled, n, h, w, c, code, S())
+    torch.cuda.synchronize()
+    assert rel_l2(rmd.cpu(), rm_ref) < 1e-5 and rel_l2(rvd.cpu(), rv_ref) < 1e-5, "running stats"
+    check(from_nhwc(full, c, c), a.detach(), dt, "bn+relu")
+    if pool:
+        check(from_nhwc(pooled, c), outs[1].detach(), dt, "maxpool")
+
+    # backward
+    da = rnd(dt, n, c, h, w, gen=g) * keep
+    dp = rnd(dt, n, c, h // 2, w // 2, gen=g) if pool else None
+    loss = (a * da).sum() + ((outs[1] * dp).sum() if pool else 0)
+    loss.backward()
+    nblk = L.call("fea_bn_bwd_blocks", n, h, w, c)
+    part = torch.full((nblk, c, 2), float("nan"), device=DEV)
+    dad = to_nhwc(da, dt, ld=ld, off=c)
+    dpd = to_nhwc(dp, dt) if pool else None
+    L.call("fea_bn_relu_bwd_reduce", view_ptr(dad, c), ld, dpd, yd, scale, shift, smean, sinv, part, n, h, w, c, code, S())
+    dgamma, dbeta, coef = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty(c, 2, device=DEV)
+    L.call("fea_bn_bwd_finalize", part, nblk, n * h * w, gamma.to(DEV), sinv, dgamma, dbeta, coef, c, S())
+    dy = torch.full((n, h, w, c), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_bn_relu_bwd_apply", view_ptr(dad, c), ld, dpd, yd, scale, shift, smean, sinv, coef, dy, part, n, h, w, c, code, S())
+    dbias = torch.empty(c, device=DEV)
+    L.call("fea_reduce_partials", part, nblk, c, 0, dbias, S())
+    torch.cuda.synchronize()
+    assert rel_l2(dgamma.cpu(), gr.grad) < 2e-4 and rel_l2(dbeta.cpu(), br.grad) < 2e-4
+    if pool:
+        # only windows whose maximum is unique after rounding are comparable
+        pass
+    check(from_nhwc(dy, c), yr.grad, dt, "bn+relu(+pool) backward", scale=3.0)
+    # conv-bias gradient under BN is rounding noise around 0
+    assert dbias.abs().max().item() < 1e-2 * (yr.grad.abs().sum((0, 2, 3)).max().item() + 1e-6)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("ncls", [6, 1, 11])
+def test_head_forward_backward(dt, ncls):
+    n, h, w = 2, 24, 40
+    g = torch.Generator().manual_seed(6)
+    code = L.dt_code(dt)
+    a = rnd(dt, n, 64, h, w, gen=g)
+    wt = torch.randn(ncls, 64, 1, 1, generator=g) / 8
+    bias = torch.randn(ncls, generator=g)
+    ar, wr, br = a.clone().requires_grad_(True), wt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = F.conv2d(ar, wr, br)
+    logits = torch.full((n, ncls, h, w), float("nan"), device=DEV)
+    ad = to_nhwc(a, dt)
+    L.call("fea_head_fwd", ad, 64, wt.to(DEV), bias.to(DEV), logits, n, h, w, 64, ncls, code, S())
+    torch.cuda.synchronize()
+    assert rel_l2(logits.cpu(), ref.detach()) < 1e-5        # fp32 math on both sides
+    dl = torch.randn(n, ncls, h, w, generator=g)
+    ref.backward(dl)
+    nblk = L.call("fea_head_bwd_blocks", n, h, w)
+    part = torch.empty(nblk * ncls * 65, device=DEV)
+    da = torch.full((n, h, w, 64), float("nan"), dtype=dt, device=DEV)
+    dW, db = torch.empty(ncls, 64, device=DEV), torch.empty(ncls, device=DEV)
+    L.call("fea_head_bwd", dl.to(DEV), ad, 64, wt.to(DEV), da, 64, part, n, h, w, 64, ncls, code, S())
+    L.call("fea_head_bwd_finalize", part, nblk, dW, db, 64, ncls, S())
+    torch.cuda.synchronize()
+    check(from_nhwc(da, 64), ar.grad, dt, "head bwd data")
+    assert rel_l2(dW.cpu(), wr.grad.reshape(ncls, 64)) < 1e-5
+    assert rel_l2(db.cpu(), br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 32, 48), (1, 1, 16, 16), (3, 6, 128, 96)])
+def test_loss_mask_iou(shape):
+    """BCE+Dice loss and its gradient within fp32 tolerance; mask and IoU
+    counts BIT-EXACT (integer work) against torch boolean ops on identical logits."""
+    from oracle import unet_oracle as O
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(7)
+    logits = torch.randn(n, c, h, w, generator=g) * 3
+    logits[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1e-30, -1e-30])      # threshold edge cases
+    target = (torch.rand(n, c, h, w, generator=g) < 0.1).to(torch.uint8)
+    lr = logits.clone().requires_grad_(True)
+    ref_loss = O.bce_dice_loss(lr, target)
+    ref_loss.backward()
+    ld, td = logits.to(DEV), target.to(DEV)
+    nblk = L.call("fea_loss_blocks", n, c, h * w)
+    part = torch.empty(nblk * 4, device=DEV)
+    sums = torch.empty(c, 4, dtype=torch.float64, device=DEV)
+    loss = torch.empty(1, device=DEV)
+    dl = torch.empty_like(ld)
+    L.call("fea_bce_dice_sums", ld, td, sums, part, n, c, h * w, S())
+    L.call("fea_bce_dice_grad", ld, td, sums, loss, dl, 1.0, n, c, h * w, S())
+    mask = torch.full((n, c, h, w), 7, dtype=torch.uint8, device=DEV)
+    inter = torch.zeros(c, dtype=torch.int64, device=DEV)
+    union = torch.zeros(c, dtype=torch.int64, device=DEV)
+    L.call("fea_mask_iou", ld, td, mask, inter, union, n, c, h * w, S())
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5 * abs(ref_loss.item())
+    assert rel_l2(dl.cpu(), lr.grad) < 1e-4
+    pm, pi, pu = O.mask_iou_counts(logits, target)
+    assert torch.equal(mask.cpu(), pm)
+    assert torch.equal(inter.cpu(), pi) and torch.equal(union.cpu(), pu)
+    grey = torch.randint(0, 256, (1000,), dtype=torch.uint8, generator=g)
+    out = torch.empty(1000, dtype=torch.uint8, device=DEV)
+    L.call("fea_binarise", grey.to(DEV), out, 1000, S())
+    assert torch.equal(out.cpu(), O.binarise_mask(grey))
+
+
+def test_bad_arguments_are_rejected():
+    x = torch.zeros(64, device=DEV)
+    with pytest.raises(L.FeaError):
+        L.call("fea_conv3x3", x, 48, x, None, x, 64, None, 1, 8, 8, 48, 64, L.F32, S())       # Cin % 32
+    with pytest.raises(L.FeaError):
+        L.call("fea_conv3x3", None, 64, x, None, x, 64, None, 1, 8, 8, 64, 64, L.F32, S())     # null
+    with pytest.raises(L.FeaError):
+        L.call("fea_head_fwd", x, 64, x, x, x, 1, 8, 8, 64, 17, L.F32, S())                    # too many classes
+    with pytest.raises(L.FeaError):
+        L.call("fea_conv3x3_wgrad", x, 64, x, 64, x, x, 16, 1, 8, 8, 64, 64, L.F32, S())      # workspace too small
