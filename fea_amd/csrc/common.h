@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // Activations and packed weights are stored as "128-byte channel rows": one
 // row holds CK consecutive channels of one pixel (or of one output channel of
@@ -23,9 +24,13 @@ template <> struct Elem<__bf16> { static constexpr int CK = 64; static constexpr
 // bf16 -> one 32x32x16 MFMA, fp32 -> four exact-f32 32x32x2 MFMAs.  A and B use
 // the same lane->k map, so any consistent k order is correct.
 __device__ __forceinline__ void mma16(f32x16& acc, const u32x4& a, const u32x4& b, const float*) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[t]), __builtin_bit_cast(float, b[t]), acc, 0, 0, 0);
+    // NOTE: bit-cast the WHOLE vector, then index.  `__builtin_bit_cast(float, a[t])`
+    // on a vector element is miscompiled by hipcc 7.2 (every t reads element 0).
+    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma16(f32x16& acc, const u32x4& a, const u32x4& b, const __bf16*) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);

@@ -8,8 +8,8 @@ template <typename T> struct Vec { static constexpr int N = 16 / sizeof(T); };
 
 template <typename T> __device__ __forceinline__ void unpack(const u32x4& v, float* f);
 template <> __device__ __forceinline__ void unpack<float>(const u32x4& v, float* f) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) f[j] = __builtin_bit_cast(float, v[j]);
+    const f32x4 t = __builtin_bit_cast(f32x4, v);      // whole-vector cast (see common.h note)
+    f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
 }
 template <> __device__ __forceinline__ void unpack<__bf16>(const u32x4& v, float* f) {
     const bf16x8 b = __builtin_bit_cast(bf16x8, v);
@@ -18,10 +18,9 @@ template <> __device__ __forceinline__ void unpack<__bf16>(const u32x4& v, float
 }
 template <typename T> __device__ __forceinline__ u32x4 pack(const float* f);
 template <> __device__ __forceinline__ u32x4 pack<float>(const float* f) {
-    u32x4 v;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(uint32_t, f[j]);
-    return v;
+    f32x4 t;
+    t.x = f[0]; t.y = f[1]; t.z = f[2]; t.w = f[3];
+    return __builtin_bit_cast(u32x4, t);
 }
 template <> __device__ __forceinline__ u32x4 pack<__bf16>(const float* f) {
     bf16x8 b;

@@ -5,9 +5,8 @@
 // 8 lanes cooperate on one pixel: lane `sub` owns input channels 8*sub..8*sub+7.
 template <typename T> __device__ __forceinline__ void load8(const T* p, float* f);
 template <> __device__ __forceinline__ void load8<float>(const float* p, float* f) {
-    const u32x4 a = *reinterpret_cast<const u32x4*>(p), b = *reinterpret_cast<const u32x4*>(p + 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { f[j] = __builtin_bit_cast(float, a[j]); f[4 + j] = __builtin_bit_cast(float, b[j]); }
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 template <> __device__ __forceinline__ void load8<__bf16>(const __bf16* p, float* f) {
     const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
@@ -16,10 +15,9 @@ template <> __device__ __forceinline__ void load8<__bf16>(const __bf16* p, float
 }
 template <typename T> __device__ __forceinline__ void store8(T* p, const float* f);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float* f) {
-    u32x4 a, b;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { a[j] = __builtin_bit_cast(uint32_t, f[j]); b[j] = __builtin_bit_cast(uint32_t, f[4 + j]); }
-    *reinterpret_cast<u32x4*>(p) = a; *reinterpret_cast<u32x4*>(p + 4) = b;
+    f32x4 a, b;
+    a.x = f[0]; a.y = f[1]; a.z = f[2]; a.w = f[3]; b.x = f[4]; b.y = f[5]; b.z = f[6]; b.w = f[7];
+    *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 template <> __device__ __forceinline__ void store8<__bf16>(__bf16* p, const float* f) {
     bf16x8 b;

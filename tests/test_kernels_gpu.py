@@ -215,7 +215,7 @@ def test_bn_relu_pool_forward_backward(dt, shape):
     n, h, w, c, pool = shape
     g = torch.Generator().manual_seed(5)
     code = L.dt_code(dt)
-    y = rnd(dt, n, c, h, w, gen=g) * 2 + 0.3
+    y = (rnd(dt, n, c, h, w, gen=g) * 2 + 0.3).to(dt).float()
     gamma = torch.rand(c, generator=g) + 0.5
     gamma[::7] *= -1                                   # negative gamma must work too
     beta = torch.randn(c, generator=g) * 0.2
