@@ -1,0 +1,413 @@
+"""Host-side orchestration of the UNet forward/backward on the HIP kernels.
+
+`UNetEngine` owns, per input shape, a *plan*: every activation / gradient /
+workspace buffer laid out once in HBM (NHWC, compute dtype), so that steady
+state training performs no allocation.  It mirrors, op for op, the dataflow of
+the reference's `FloorPlanSegmentationModel.forward` (data_model/models.py:36-46)
+and of its autograd backward (triggered at train_direct.py:104).
+
+Data layout in HBM (N = batch, level l has spatial H/2^l x W/2^l):
+  xcol            [N,H,W,Kpad]        3x3 im2col rows of the NCHW fp32 input
+  y[layer]        [N,h,w,Cout]        raw conv output (pre-BN), kept for backward
+  a[X.0]          [N,h,w,Cout]        relu(bn(y)) of the first conv of a block
+  cat[k]          [N,h,w,2C]          concat buffer: upconv_k writes channels [0,C),
+                                      enc_k.3's BN+ReLU writes the skip into [C,2C)
+                                      (torch.cat([up, skip]) of models.py:42-45 is free)
+  pool[k]         [N,h/2,w/2,C]       maxpool of the skip, input of the next encoder block
+  a[dec_k.3], a[bottleneck.3]         dense
+  dcat[k]         like cat[k]         gradient of the concat buffer (skip half lives until
+                                      the encoder backward reaches level k)
+  G0,G1,gmid,dY   N*H*W*64 elements   rotating gradient buffers
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+KPAD_ALIGN = 64
+
+ENC = ["enc1", "enc2", "enc3", "enc4"]
+CH = {"enc1": 64, "enc2": 128, "enc3": 256, "enc4": 512, "bottleneck": 1024,
+      "dec4": 512, "dec3": 256, "dec2": 128, "dec1": 64}
+LEVEL = {"enc1": 0, "enc2": 1, "enc3": 2, "enc4": 3, "bottleneck": 4, "dec4": 3, "dec3": 2, "dec2": 1, "dec1": 0}
+BLOCKS = ["enc1", "enc2", "enc3", "enc4", "bottleneck", "dec4", "dec3", "dec2", "dec1"]
+
+
+def param_order(module) -> List[str]:
+    """Parameter names in REVERSE-forward order: the order in which backward
+    finishes their gradients (out, dec1, upconv1, dec2, ..., enc1).  The flat
+    gradient buffer uses this order so that finished gradients form a growing
+    prefix that can be all-reduced while backward continues."""
+    names = ["out.weight", "out.bias"]
+    for blk, up in (("dec1", "upconv1"), ("dec2", "upconv2"), ("dec3", "upconv3"), ("dec4", "upconv4")):
+        for idx in (3, 0):
+            names += [f"{blk}.{idx}.weight", f"{blk}.{idx}.bias", f"{blk}.{idx + 1}.weight", f"{blk}.{idx + 1}.bias"]
+        names += [f"{up}.weight", f"{up}.bias"]
+    for blk in ("bottleneck", "enc4", "enc3", "enc2", "enc1"):
+        for idx in (3, 0):
+            names += [f"{blk}.{idx}.weight", f"{blk}.{idx}.bias", f"{blk}.{idx + 1}.weight", f"{blk}.{idx + 1}.bias"]
+    return names
+
+
+class _Plan:
+    """All device buffers for one (N, H, W) problem."""
+
+    def __init__(self, eng: "UNetEngine", N: int, H: int, W: int):
+        dt, dev = eng.dtype, eng.device
+        self.N, self.H, self.W = N, H, W
+        self.dims = [(H >> l, W >> l) for l in range(5)]
+        es = torch.empty
+        self.xcol = es((N, H, W, eng.kpad), dtype=dt, device=dev)
+        self.y: Dict[str, torch.Tensor] = {}
+        self.a0: Dict[str, torch.Tensor] = {}
+        self.a3: Dict[str, torch.Tensor] = {}
+        self.cat: Dict[int, torch.Tensor] = {}
+        self.dcat: Dict[int, torch.Tensor] = {}
+        self.pool: Dict[int, torch.Tensor] = {}
+        max_stats = 0
+        for blk in BLOCKS:
+            h, w = self.dims[LEVEL[blk]]
+            c = CH[blk]
+            for idx in (0, 3):
+                self.y[f"{blk}.{idx}"] = es((N, h, w, c), dtype=dt, device=dev)
+            self.a0[blk] = es((N, h, w, c), dtype=dt, device=dev)
+            if blk not in ENC:
+                self.a3[blk] = es((N, h, w, c), dtype=dt, device=dev)
+            max_stats = max(max_stats, L.call("fea_conv_num_tiles", N, h, w) * c * 2)
+        for k, blk in enumerate(ENC, start=1):
+            h, w = self.dims[k - 1]
+            c = CH[blk]
+            self.cat[k] = es((N, h, w, 2 * c), dtype=dt, device=dev)
+            self.pool[k] = es((N, h // 2, w // 2, c), dtype=dt, device=dev)
+        self.stats = es(max_stats, dtype=torch.float32, device=dev)
+        self.logits = es((N, eng.num_classes, H, W), dtype=torch.float32, device=dev)
+        # per-layer BN coefficients (kept from forward to backward)
+        self.coef: Dict[str, Dict[str, torch.Tensor]] = {}
+        for blk in BLOCKS:
+            for idx in (0, 3):
+                c = CH[blk]
+                self.coef[f"{blk}.{idx}"] = {k: es(c, dtype=torch.float32, device=dev)
+                                             for k in ("scale", "shift", "mean", "invstd")}
+        self.bwd_ready = False
+
+    def alloc_backward(self, eng: "UNetEngine"):
+        if self.bwd_ready:
+            return
+        dt, dev = eng.dtype, eng.device
+        N, H, W = self.N, self.H, self.W
+        es = torch.empty
+        big = N * H * W * 64
+        self.G = [es(big, dtype=dt, device=dev) for _ in range(2)]
+        self.gmid = es(big, dtype=dt, device=dev)
+        self.dY = es(big, dtype=dt, device=dev)
+        for k, blk in enumerate(ENC, start=1):
+            h, w = self.dims[k - 1]
+            self.dcat[k] = es((N, h, w, 2 * CH[blk]), dtype=dt, device=dev)
+        code = eng.code
+        ws = 0
+        lib = L.load()
+        for blk in BLOCKS:
+            h, w = self.dims[LEVEL[blk]]
+            c = CH[blk]
+            cin0 = eng.block_cin(blk)
+            if blk == "enc1":
+                ws = max(ws, lib.fea_wgrad_ws_bytes(1, N, h, w, c, eng.kpad, code))
+            else:
+                ws = max(ws, lib.fea_wgrad_ws_bytes(0, N, h, w, c, cin0, code))
+            ws = max(ws, lib.fea_wgrad_ws_bytes(0, N, h, w, c, c, code))
+        for k in (1, 2, 3, 4):
+            h, w = self.dims[k]
+            c = CH[ENC[k - 1]]
+            ws = max(ws, lib.fea_wgrad_ws_bytes(2, N, h, w, 2 * c, c, code))
+        self.ws_bytes = int(ws)
+        self.ws = es(self.ws_bytes // 4, dtype=torch.float32, device=dev)
+        nb = max(L.call("fea_bn_bwd_blocks", N, *self.dims[LEVEL[b]], CH[b]) * CH[b] * 2 for b in BLOCKS)
+        nb = max(nb, 2048 * 1024 * 2)
+        self.part = es(nb, dtype=torch.float32, device=dev)
+        self.bncoef = es(1024 * 2, dtype=torch.float32, device=dev)
+        self.head_part = es(L.call("fea_head_bwd_blocks", N, H, W) * eng.num_classes * 65, dtype=torch.float32, device=dev)
+        self.bwd_ready = True
+
+
+class UNetEngine:
+    def __init__(self, module, compute_dtype: torch.dtype):
+        self.m = module
+        self.dtype = compute_dtype
+        self.code = L.dt_code(compute_dtype)
+        self.in_channels = module.in_channels
+        self.num_classes = module.num_classes
+        self.kpad = (9 * self.in_channels + KPAD_ALIGN - 1) // KPAD_ALIGN * KPAD_ALIGN
+        self.device = None
+        self.plans: Dict[tuple, _Plan] = {}
+        self.packed: Dict[str, torch.Tensor] = {}
+        self.packed_ver: Dict[str, int] = {}
+        self.flat_grad: Optional[torch.Tensor] = None
+        self.grad_views: Dict[str, torch.Tensor] = {}
+        self.grad_offsets: Dict[str, tuple] = {}
+        # called as grad_ready(name) right after the kernels that finish a
+        # parameter's gradient have been enqueued (used for overlapped all-reduce)
+        self.grad_ready: Optional[Callable[[str], None]] = None
+        self.debug_taps: Optional[dict] = None
+        L.load()
+
+    # ------------------------------------------------------------------ utils
+    def block_cin(self, blk: str) -> int:
+        return {"enc1": self.in_channels, "enc2": 64, "enc3": 128, "enc4": 256, "bottleneck": 512,
+                "dec4": 1024, "dec3": 512, "dec2": 256, "dec1": 128}[blk]
+
+    def _params(self) -> Dict[str, torch.nn.Parameter]:
+        return dict(self.m.named_parameters())
+
+    def _bufs(self) -> Dict[str, torch.Tensor]:
+        return dict(self.m.named_buffers())
+
+    def _ensure_device(self, x: torch.Tensor):
+        if self.device != x.device:
+            self.device = x.device
+            self.plans.clear()
+            self.packed.clear()
+            self.packed_ver.clear()
+            self.flat_grad = None
+
+    def plan(self, N, H, W) -> _Plan:
+        key = (N, H, W)
+        p = self.plans.get(key)
+        if p is None:
+            if len(self.plans) >= 2:          # keep at most two shapes resident
+                self.plans.pop(next(iter(self.plans)))
+            p = _Plan(self, N, H, W)
+            self.plans[key] = p
+        return p
+
+    def _ensure_flat_grad(self):
+        if self.flat_grad is not None:
+            return
+        params = self._params()
+        order = param_order(self.m)
+        assert set(order) == set(params), "parameter set differs from the reference's"
+        off = 0
+        for n in order:
+            numel = params[n].numel()
+            self.grad_offsets[n] = (off, numel)
+            off += (numel + 63) // 64 * 64           # 256-byte aligned slices
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad_views = {n: self.flat_grad[o:o + k].view(params[n].shape) for n, (o, k) in self.grad_offsets.items()}
+
+    # -------------------------------------------------------------- packing
+    def _pack(self, key: str, param: torch.nn.Parameter, numel: int, fn: str, *args):
+        ver = param._version
+        buf = self.packed.get(key)
+        if buf is None:
+            buf = torch.empty(numel, dtype=self.dtype, device=self.device)
+            self.packed[key] = buf
+            self.packed_ver[key] = -1
+        if self.packed_ver[key] != (ver, param.data_ptr()):
+            L.call(fn, param.detach(), buf, *args, self.code, L.stream_ptr())
+            self.packed_ver[key] = (ver, param.data_ptr())
+        return buf
+
+    def _w_fwd(self, name: str):
+        p = self._params()[name + ".weight"]
+        if name == "enc1.0":
+            return self._pack(name + "/f", p, 64 * self.kpad, "fea_pack_conv3x3_im2col", 64, self.in_channels, self.kpad)
+        co, ci = p.shape[0], p.shape[1]
+        return self._pack(name + "/f", p, p.numel(), "fea_pack_conv3x3", co, ci, 0)
+
+    def _w_dgrad(self, name: str):
+        p = self._params()[name + ".weight"]
+        co, ci = p.shape[0], p.shape[1]
+        return self._pack(name + "/d", p, p.numel(), "fea_pack_conv3x3", co, ci, 1)
+
+    def _w_up(self, name: str, bwd: int):
+        p = self._params()[name + ".weight"]
+        ci, co = p.shape[0], p.shape[1]
+        return self._pack(name + ("/b" if bwd else "/f"), p, p.numel(), "fea_pack_upconv2x2", ci, co, bwd)
+
+    # -------------------------------------------------------------- forward
+    def forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
+        if not x.is_cuda:
+            raise L.FeaError("fea_amd runs on a ROCm device only (no CPU fallback): move the module and input to 'cuda'")
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected input [N,{self.in_channels},H,W], got {tuple(x.shape)}")
+        N, _, H, W = x.shape
+        if H % 16 or W % 16:
+            # the reference fails at the first torch.cat for such sizes
+            raise RuntimeError(f"Sizes of tensors must match: H and W must be multiples of 16, got {H}x{W}")
+        self._ensure_device(x)
+        x = x.detach().contiguous().float()
+        pl = self.plan(N, H, W)
+        P, B = self._params(), self._bufs()
+        S = L.stream_ptr()
+        code = self.code
+        taps = self.debug_taps
+
+        L.call("fea_im2col3x3_nchw", x, pl.xcol, N, self.in_channels, H, W, self.kpad, code, S)
+
+        def conv_bn(name, inp, ld_in, cin, h, w, cout, out_full, ld_full, out_pool):
+            """conv -> BN statistics -> scale/shift -> ReLU(+pool)"""
+            y = pl.y[name]
+            stats = pl.stats if training else None
+            wp = self._w_fwd(name)
+            bias = P[name + ".bias"]
+            if name == "enc1.0":
+                L.call("fea_conv1x1", inp, ld_in, wp, bias, y, cout, stats, N, h, w, self.kpad, cout, code, S)
+            else:
+                L.call("fea_conv3x3", inp, ld_in, wp, bias, y, cout, stats, N, h, w, cin, cout, code, S)
+            blk, idx = name.rsplit(".", 1)
+            bn = f"{blk}.{int(idx) + 1}"
+            cf = pl.coef[name]
+            if training:
+                ntiles = L.call("fea_conv_num_tiles", N, h, w)
+                L.call("fea_bn_finalize", stats, ntiles, N * h * w, P[bn + ".weight"], P[bn + ".bias"],
+                       B[bn + ".running_mean"], B[bn + ".running_var"], BN_MOMENTUM, BN_EPS,
+                       cf["scale"], cf["shift"], cf["mean"], cf["invstd"], cout, S)
+            else:
+                L.call("fea_bn_eval_coeffs", P[bn + ".weight"], P[bn + ".bias"], B[bn + ".running_mean"],
+                       B[bn + ".running_var"], BN_EPS, cf["scale"], cf["shift"], cout, S)
+            L.call("fea_bn_relu_pool", y, cf["scale"], cf["shift"], out_full, ld_full, out_pool, N, h, w, cout, code, S)
+
+        es = x.element_size() if False else torch.empty(0, dtype=self.dtype).element_size()
+
+        def off_ptr(t: torch.Tensor, ch_off: int) -> int:
+            return t.data_ptr() + ch_off * es
+
+        # encoder
+        inp, ld_in, cin = pl.xcol, self.kpad, self.kpad
+        for k, blk in enumerate(ENC, start=1):
+            h, w = pl.dims[k - 1]
+            c = CH[blk]
+            conv_bn(f"{blk}.0", inp, ld_in, cin, h, w, c, pl.a0[blk], c, None)
+            conv_bn(f"{blk}.3", pl.a0[blk], c, c, h, w, c, off_ptr(pl.cat[k], c), 2 * c, pl.pool[k])
+            inp, ld_in, cin = pl.pool[k], c, c
+        h, w = pl.dims[4]
+        conv_bn("bottleneck.0", inp, 512, 512, h, w, 1024, pl.a0["bottleneck"], 1024, None)
+        conv_bn("bottleneck.3", pl.a0["bottleneck"], 1024, 1024, h, w, 1024, pl.a3["bottleneck"], 1024, None)
+        d, cd = pl.a3["bottleneck"], 1024
+        # decoder
+        for k in (4, 3, 2, 1):
+            blk = f"dec{k}"
+            hl, wl = pl.dims[k]            # low-res dims (input of the transposed conv)
+            h, w = pl.dims[k - 1]
+            c = CH[blk]
+            L.call("fea_upconv2x2_fwd", d, cd, self._w_up(f"upconv{k}", 0), P[f"upconv{k}.bias"], pl.cat[k], 2 * c,
+                   N, hl, wl, cd, c, code, S)
+            conv_bn(f"{blk}.0", pl.cat[k], 2 * c, 2 * c, h, w, c, pl.a0[blk], c, None)
+            conv_bn(f"{blk}.3", pl.a0[blk], c, c, h, w, c, pl.a3[blk], c, None)
+            d, cd = pl.a3[blk], c
+        L.call("fea_head_fwd", d, 64, P["out.weight"], P["out.bias"], pl.logits, N, H, W, 64, self.num_classes, code, S)
+        if training:
+            torch._foreach_add_([B[f"{b}.{i}.num_batches_tracked"] for b in BLOCKS for i in (1, 4)], 1)
+        if taps is not None:
+            self._export_taps(pl, taps)
+        self._last = (pl, training)
+        return pl.logits
+
+    def _export_taps(self, pl: _Plan, taps: dict):
+        """Debug/test hook: activated outputs (NCHW fp32) of every conv layer."""
+        for blk in BLOCKS:
+            c = CH[blk]
+            taps[f"{blk}.0.act"] = pl.a0[blk].float().permute(0, 3, 1, 2).contiguous()
+            taps[f"{blk}.0.conv"] = pl.y[f"{blk}.0"].float().permute(0, 3, 1, 2).contiguous()
+            taps[f"{blk}.3.conv"] = pl.y[f"{blk}.3"].float().permute(0, 3, 1, 2).contiguous()
+            if blk in ENC:
+                k = ENC.index(blk) + 1
+                taps[f"{blk}.3.act"] = pl.cat[k][..., c:].float().permute(0, 3, 1, 2).contiguous()
+            else:
+                taps[f"{blk}.3.act"] = pl.a3[blk].float().permute(0, 3, 1, 2).contiguous()
+
+    # -------------------------------------------------------------- backward
+    def backward(self, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Gradients of every parameter for upstream gradient `dlogits`
+        ([N,classes,H,W] fp32).  Returns views into the flat gradient buffer."""
+        pl, training = self._last
+        if not training:
+            raise L.FeaError("backward through eval-mode BatchNorm is not supported (the reference trains in train() mode)")
+        pl.alloc_backward(self)
+        self._ensure_flat_grad()
+        N, H, W = pl.N, pl.H, pl.W
+        P = self._params()
+        S = L.stream_ptr()
+        code = self.code
+        g = self.grad_views
+        dl = dlogits.detach().contiguous().float()
+        es = torch.empty(0, dtype=self.dtype).element_size()
+
+        def off_ptr(t, ch_off):
+            return t.data_ptr() + ch_off * es
+
+        def done(*names):
+            if self.grad_ready is not None:
+                for n in names:
+                    self.grad_ready(n)
+
+        def bn_bwd(name, da_full, ld_da, dpool, h, w, c):
+            blk, idx = name.rsplit(".", 1)
+            bn = f"{blk}.{int(idx) + 1}"
+            cf = pl.coef[name]
+            y = pl.y[name]
+            nblk = L.call("fea_bn_bwd_blocks", N, h, w, c)
+            L.call("fea_bn_relu_bwd_reduce", da_full, ld_da, dpool, y, cf["scale"], cf["shift"], cf["mean"], cf["invstd"],
+                   pl.part, N, h, w, c, code, S)
+            L.call("fea_bn_bwd_finalize", pl.part, nblk, N * h * w, P[bn + ".weight"], cf["invstd"],
+                   g[bn + ".weight"], g[bn + ".bias"], pl.bncoef, c, S)
+            L.call("fea_bn_relu_bwd_apply", da_full, ld_da, dpool, y, cf["scale"], cf["shift"], cf["mean"], cf["invstd"],
+                   pl.bncoef, pl.dY, pl.part, N, h, w, c, code, S)
+            L.call("fea_reduce_partials", pl.part, nblk, c, 0, g[name + ".bias"], S)
+
+        def block_bwd(blk, da_full, ld_da, dpool, inp, ld_in, cin, d_in, ld_din):
+            h, w = pl.dims[LEVEL[blk]]
+            c = CH[blk]
+            n3, n0 = f"{blk}.3", f"{blk}.0"
+            bn_bwd(n3, da_full, ld_da, dpool, h, w, c)
+            L.call("fea_conv3x3_wgrad", pl.dY, c, pl.a0[blk], c, g[n3 + ".weight"], pl.ws, pl.ws_bytes, N, h, w, c, c, code, S)
+            done(n3 + ".weight", n3 + ".bias", f"{blk}.4.weight", f"{blk}.4.bias")
+            L.call("fea_conv3x3", pl.dY, c, self._w_dgrad(n3), None, pl.gmid, c, None, N, h, w, c, c, code, S)
+            bn_bwd(n0, pl.gmid, c, None, h, w, c)
+            if blk == "enc1":
+                L.call("fea_conv1x1_im2col_wgrad", pl.dY, c, pl.xcol, self.kpad, g[n0 + ".weight"], pl.ws, pl.ws_bytes,
+                       N, h, w, self.kpad, self.in_channels, c, code, S)
+            else:
+                L.call("fea_conv3x3_wgrad", pl.dY, c, inp, ld_in, g[n0 + ".weight"], pl.ws, pl.ws_bytes, N, h, w, cin, c, code, S)
+            done(n0 + ".weight", n0 + ".bias", f"{blk}.1.weight", f"{blk}.1.bias")
+            if d_in is not None:
+                L.call("fea_conv3x3", pl.dY, c, self._w_dgrad(n0), None, d_in, ld_din, None, N, h, w, c, cin, code, S)
+
+        # head
+        nblk = L.call("fea_head_bwd_blocks", N, H, W)
+        L.call("fea_head_bwd", dl, pl.a3["dec1"], 64, P["out.weight"], pl.G[0], 64, pl.head_part, N, H, W, 64, self.num_classes, code, S)
+        L.call("fea_head_bwd_finalize", pl.head_part, nblk, g["out.weight"], g["out.bias"], 64, self.num_classes, S)
+        done("out.weight", "out.bias")
+        # decoder
+        for k in (1, 2, 3, 4):
+            blk = f"dec{k}"
+            c = CH[blk]
+            block_bwd(blk, pl.G[0], c, None, pl.cat[k], 2 * c, 2 * c, pl.dcat[k], 2 * c)
+            hl, wl = pl.dims[k]
+            src = pl.a3[f"dec{k + 1}"] if k < 4 else pl.a3["bottleneck"]
+            nb = ctypes.c_int(0)
+            L.call("fea_channel_sum", pl.dcat[k], 2 * c, N * 4 * hl * wl, c, pl.part, ctypes.byref(nb), code, S)
+            L.call("fea_reduce_partials", pl.part, nb.value, c, 0, g[f"upconv{k}.bias"], S)
+            L.call("fea_upconv2x2_wgrad", src, 2 * c, pl.dcat[k], 2 * c, g[f"upconv{k}.weight"], pl.ws, pl.ws_bytes,
+                   N, hl, wl, 2 * c, c, code, S)
+            done(f"upconv{k}.weight", f"upconv{k}.bias")
+            L.call("fea_upconv2x2_bwd_data", pl.dcat[k], 2 * c, self._w_up(f"upconv{k}", 1), pl.G[0], 2 * c,
+                   N, hl, wl, 2 * c, c, code, S)
+        # bottleneck and encoder
+        block_bwd("bottleneck", pl.G[0], 1024, None, pl.pool[4], 512, 512, pl.G[1], 512)
+        cur = 1
+        for k in (4, 3, 2, 1):
+            blk = ENC[k - 1]
+            c = CH[blk]
+            if k > 1:
+                cprev = CH[ENC[k - 2]]
+                block_bwd(blk, off_ptr(pl.dcat[k], c), 2 * c, pl.G[cur], pl.pool[k - 1], cprev, cprev, pl.G[1 - cur], cprev)
+            else:
+                block_bwd(blk, off_ptr(pl.dcat[k], c), 2 * c, pl.G[cur], pl.xcol, self.kpad, self.kpad, None, 0)
+            cur = 1 - cur
+        return g

@@ -1,0 +1,152 @@
+"""Drop-in replacement for the reference's UNet.
+
+`FloorPlanSegmentationModel` keeps the reference's constructor, forward
+signature, sub-module attribute names and `state_dict` layout
+(/root/reference/data_model/models.py:6-46), so checkpoints and callers
+(`FloorPlanTo3DPipeline`, models.py:183,190) work unchanged.  Parameters live in
+ordinary `nn.Conv2d` / `nn.BatchNorm2d` / `nn.ConvTranspose2d` containers
+(identical init RNG consumption, fp32 OIHW master weights, optimizer
+behaviour); the arithmetic of `forward` and of its backward runs in the HIP
+kernels of libfea_unet.so through `fea_amd.engine.UNetEngine`.
+
+There is no CPU execution path: calling the module on a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .engine import UNetEngine
+
+
+def _resolve_dtype(compute_dtype) -> torch.dtype:
+    if compute_dtype is None:
+        compute_dtype = os.environ.get("FEA_AMD_DTYPE", "fp32")
+    if isinstance(compute_dtype, torch.dtype):
+        if compute_dtype in (torch.float32, torch.bfloat16):
+            return compute_dtype
+        raise ValueError(f"unsupported compute dtype {compute_dtype}")
+    table = {"fp32": torch.float32, "float32": torch.float32, "f32": torch.float32,
+             "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+    try:
+        return table[str(compute_dtype).lower()]
+    except KeyError:
+        raise ValueError(f"unsupported compute dtype {compute_dtype!r} (use 'fp32' or 'bf16')") from None
+
+
+class _UNetFunction(torch.autograd.Function):
+    """One autograd node for the whole UNet: forward enqueues the HIP forward,
+    backward the HIP backward, and returns the parameter gradients in the
+    order the parameters were passed."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        eng = module._engine()
+        logits = eng.forward(x, module.training)
+        ctx.module = module
+        ctx.names = module._param_names
+        # hand out a copy: the plan's logits buffer is overwritten by the next forward
+        return logits.clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        module = ctx.module
+        grads = module._engine().backward(dlogits)
+        out = tuple(grads[n] if p.requires_grad else None
+                    for n, p in zip(ctx.names, module.parameters()))
+        return (None, None) + out
+
+
+class FloorPlanSegmentationModel(nn.Module):
+    """U-Net for segmenting walls, doors, windows, rooms (reference
+    models.py:6).  `compute_dtype` ('fp32' default, or 'bf16'; env
+    FEA_AMD_DTYPE) selects the storage type of activations and packed
+    weights inside the HIP path; parameters, gradients and logits are fp32."""
+
+    def __init__(self, in_channels=3, num_classes=6, *, compute_dtype=None):
+        super().__init__()
+        # construction order == reference order (models.py:10-24): it fixes
+        # which RNG draws initialise which weight and the state_dict order
+        self.enc1 = self._conv_block(in_channels, 64)
+        self.enc2 = self._conv_block(64, 128)
+        self.enc3 = self._conv_block(128, 256)
+        self.enc4 = self._conv_block(256, 512)
+        self.bottleneck = self._conv_block(512, 1024)
+        self.upconv4 = nn.ConvTranspose2d(1024, 512, 2, stride=2)
+        self.dec4 = self._conv_block(1024, 512)
+        self.upconv3 = nn.ConvTranspose2d(512, 256, 2, stride=2)
+        self.dec3 = self._conv_block(512, 256)
+        self.upconv2 = nn.ConvTranspose2d(256, 128, 2, stride=2)
+        self.dec2 = self._conv_block(256, 128)
+        self.upconv1 = nn.ConvTranspose2d(128, 64, 2, stride=2)
+        self.dec1 = self._conv_block(128, 64)
+        self.out = nn.Conv2d(64, num_classes, 1)
+        self.pool = nn.MaxPool2d(2)
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.compute_dtype = _resolve_dtype(compute_dtype)
+        self._param_names = [n for n, _ in self.named_parameters()]
+        self.__dict__["_eng"] = None      # not a sub-module / not in state_dict
+
+    def _conv_block(self, in_c, out_c):
+        return nn.Sequential(
+            nn.Conv2d(in_c, out_c, 3, padding=1),
+            nn.BatchNorm2d(out_c),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(out_c, out_c, 3, padding=1),
+            nn.BatchNorm2d(out_c),
+            nn.ReLU(inplace=True),
+        )
+
+    # -- engine -----------------------------------------------------------
+    def _engine(self) -> UNetEngine:
+        eng = self.__dict__.get("_eng")
+        if eng is None or eng.dtype != self.compute_dtype:
+            eng = UNetEngine(self, self.compute_dtype)
+            self.__dict__["_eng"] = eng
+        return eng
+
+    def set_compute_dtype(self, compute_dtype):
+        self.compute_dtype = _resolve_dtype(compute_dtype)
+        return self
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise L.FeaError("fea_amd.FloorPlanSegmentationModel runs on a ROCm device only; "
+                             "there is no CPU fallback (use the reference module for CPU execution)")
+        for p in self.parameters():
+            if p.dtype != torch.float32:
+                raise L.FeaError("parameters must stay fp32 (use compute_dtype='bf16' for bf16 arithmetic)")
+            break
+        in_dtype = x.dtype
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            logits = _UNetFunction.apply(self, x, *self.parameters())
+        else:
+            logits = self._engine().forward(x, self.training).clone()
+        return logits if in_dtype == torch.float32 else logits.to(in_dtype)
+
+    # -- checkpoints --------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        """Accepts the reference's spellings too: keys prefixed with `module.`
+        (saved from nn.DataParallel, train_direct.py:25,130) and/or
+        `segmentation_model.` (saved from FloorPlanTo3DPipeline, models.py:183);
+        keys of the pipeline's other sub-modules are ignored."""
+        own = set(self.state_dict().keys())
+        cleaned = {}
+        for k, v in state_dict.items():
+            kk = k
+            changed = True
+            while changed:
+                changed = False
+                for pre in ("module.", "segmentation_model."):
+                    if kk.startswith(pre):
+                        kk = kk[len(pre):]
+                        changed = True
+            if kk in own:
+                cleaned[kk] = v
+            elif kk == k and strict:
+                cleaned[kk] = v           # let nn.Module report the unexpected key
+        return super().load_state_dict(cleaned, strict=strict, assign=assign)
