@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- UNet training throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size S] [--dtype bf16|fp32]
+
+One "step" = one full training step (forward, BCE+Dice loss, backward,
+grad-clip, AdamW) of the UNet on a synthetic floor-plan batch resident in HBM.
+N>1: launched by torch.distributed.run, one rank per GPU, per-GPU batch fixed
+(weak scaling), gradients all-reduced over RCCL in buckets overlapped with
+backward.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0       # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3         # f32-input MFMA
+GFLOP_TRAIN_512 = 1156.5        # per image, fwd + dgrad + wgrad
+
+
+def train_gflop_per_image(h, w):
+    return GFLOP_TRAIN_512 * (h * w) / (512.0 * 512.0)
+
+
+def conv_flops(args):
+    # fea_conv3x3(x, ldx, w, bias, y, ldy, stats, N, H, W, Cin, Cout, dtype, stream)
+    n, h, w, cin, cout = args[7:12]
+    return 2.0 * n * h * w * cin * cout * 9
+
+
+def cpu_baseline(size, seconds_budget=25.0):
+    """The oracle (CPU port of the reference path) timed on this host's cores on
+    a bounded sample of the same workload: batch 2 at the bench resolution."""
+    from oracle import unet_oracle as O      # cpu_baseline leg only
+    torch.manual_seed(0)
+    n = 2
+    sd = O.init_state_dict(0)
+    params, bufs = O.split_state(sd)
+    x, tgt = O.synthetic_batch(n, size, size, seed=1234)
+    state = {}
+    cores = torch.get_num_threads()
+
+    def step():
+        nonlocal params, bufs
+        loss, _, grads, nb = O.loss_and_grads(params, bufs, x, tgt, training=True)
+        clipped, _ = O.clip_grad_norm(grads, 1.0)
+        params = O.adamw_step(params, clipped, state)
+        bufs = nb
+    t0 = time.time()
+    step()                                    # warm-up
+    warm = time.time() - t0
+    k = max(1, min(3, int(seconds_budget / max(warm, 1e-3)) - 1))
+    t0 = time.time()
+    for _ in range(k):
+        step()
+    dt = (time.time() - t0) / k
+    return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle train step (fwd+BCE/Dice+bwd+clip+AdamW), batch {n} @ {size}x{size} fp32, {k} timed step(s) after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local)
+    if distributed:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import fea_amd
+    from fea_amd import _lib as L
+    from fea_amd.data import synthetic_batch
+    from fea_amd.train import UNetTrainer
+
+    torch.manual_seed(0)                       # identical replicas on every rank
+    model = fea_amd.FloorPlanSegmentationModel(compute_dtype=a.dtype).cuda()
+    trainer = UNetTrainer(model, distributed=distributed)
+    x, tgt = synthetic_batch(a.batch, a.size, a.size, seed=1234 + rank)
+    x, tgt = x.cuda(), tgt.cuda()
+
+    def sync():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = trainer.step(x, tgt)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = trainer.step(x, tgt)
+    sync()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss.item())
+
+    # live per-kernel timing (HIP events on the launch stream) of the dominant kernel
+    roof = None
+    if rank == 0 and not a.no_kernel_timing:
+        L.PROFILE = []
+        for _ in range(2):
+            trainer.step(x, tgt)
+        torch.cuda.synchronize()
+        prof, L.PROFILE = L.PROFILE, None
+        per = {}
+        for name, e0, e1, args in prof:
+            ms = e0.elapsed_time(e1)
+            d = per.setdefault(name, [0.0, 0, 0.0])
+            d[0] += ms
+            d[1] += 1
+            if name == "fea_conv3x3":
+                d[2] += conv_flops(args)
+        ms, cnt, fl = per["fea_conv3x3"]
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "igemm_kernel (fea_conv3x3: conv3x3 forward + dgrad launches)",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "avg_launch_ms": ms / cnt, "launches_per_step": cnt // 2,
+                "kernel_ms_per_step": {k: v[0] / 2 for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])}}
+
+    if rank == 0:
+        ips = world * a.batch * a.steps / dt
+        gf = train_gflop_per_image(a.size, a.size)
+        out = {
+            "metric": "UNet train images/sec @512x512 bf16" if (a.size == 512 and a.dtype == "bf16")
+                      else f"UNet train images/sec @{a.size}x{a.size} {a.dtype}",
+            "value": ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"UNet (FloorPlanSegmentationModel) training step, {a.size}x{a.size}, batch {a.batch}/GPU, "
+                                   f"{a.dtype} storage / fp32 accumulate, BCE+Dice loss, clip 1.0, AdamW (BASELINE configs[2]"
+                                   f"{'/[3]' if world > 1 else ''})",
+                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "per_gpu_batch": a.batch},
+            "whole_step_tflops_per_gpu": ips / world * gf / 1e3,
+            "whole_step_mfma_frac": ips / world * gf / 1e3 / (PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS),
+            "loss": loss_val,
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.size)
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

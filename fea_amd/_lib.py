@@ -59,6 +59,10 @@ SIGNATURES = {
 }
 
 _lib = None
+# When set to a list, every `call` is bracketed by torch.cuda events on the
+# current stream and (name, ev_start, ev_end, args) is appended (bench.py's
+# live per-kernel timing).  None = no instrumentation.
+PROFILE = None
 
 
 class FeaError(RuntimeError):
@@ -110,7 +114,14 @@ def call(name: str, *args):
     lib = load()
     fn = getattr(lib, name)
     conv = [ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a for a in args]
-    rc = fn(*conv)
+    if PROFILE is not None and SIGNATURES[name][1] and SIGNATURES[name][1][-1] is P and not name.endswith(("_blocks", "_tiles")):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*conv)
+        e1.record()
+        PROFILE.append((name, e0, e1, conv))
+    else:
+        rc = fn(*conv)
     if SIGNATURES[name][0] is I and rc < 0 and not name.endswith(("_blocks", "_tiles")):
         raise FeaError(f"{name} failed ({rc}): {lib.fea_last_error().decode()}")
     return rc

@@ -158,7 +158,7 @@ def _batch_norm(x, gamma, beta, rm, rv, training, new_bufs, prefix):
     return (x - mean[None, :, None, None]) * (inv * gamma)[None, :, None, None] + beta[None, :, None, None]
 
 
-def _conv_block(x, p, b, name, training, new_bufs, taps=None):
+def _conv_block(x, p, b, name, training, new_bufs, taps=None, forced=None):
     for idx in (0, 3):
         x = F.conv2d(x, p[f"{name}.{idx}.weight"], p[f"{name}.{idx}.bias"], padding=1)
         if taps is not None:
@@ -170,7 +170,12 @@ def _conv_block(x, p, b, name, training, new_bufs, taps=None):
             new_bufs[bn + ".num_batches_tracked"] = b[bn + ".num_batches_tracked"] + 1
         else:
             new_bufs[bn + ".num_batches_tracked"] = b[bn + ".num_batches_tracked"]
-        x = torch.relu(x)
+        if forced is not None:
+            # kinks pinned: the ReLU mask comes from the implementation under
+            # test, so both sides differentiate the same smooth branch
+            x = x * forced[f"{name}.{idx}.mask"].to(x.dtype)
+        else:
+            x = torch.relu(x)
         if taps is not None:
             taps[f"{name}.{idx}.act"] = x
     return x
@@ -182,22 +187,46 @@ def _upconv(x, w, bias):
     return F.conv_transpose2d(x, w, bias, stride=2)
 
 
-def forward(params, bufs, x, training: bool = True, taps=None):
+def forced_from_taps(taps):
+    """Kink decisions (ReLU masks, max-pool arg-max) of an implementation under
+    test, from its activated outputs `taps["<layer>.act"]` (NCHW)."""
+    forced = {}
+    for k, v in taps.items():
+        if k.endswith(".act"):
+            forced[k[:-4] + ".mask"] = v > 0
+    for blk in ("enc1", "enc2", "enc3", "enc4"):
+        _, idx = F.max_pool2d(taps[f"{blk}.3.act"].float(), 2, return_indices=True)
+        forced[f"{blk}.pool_idx"] = idx
+    return forced
+
+
+def forward(params, bufs, x, training: bool = True, taps=None, forced=None):
     """models.py:36-46.  Returns (logits, new_buffers).  `x` is NCHW fp32,
-    H and W multiples of 16."""
+    H and W multiples of 16.  With `forced` (see forced_from_taps) the ReLU
+    masks and pool arg-max are taken from there instead of from this run's
+    own activations: the function is then smooth in its inputs, which is what
+    makes a 1e-4 gradient comparison meaningful (oracle/make_golden.py:
+    well_conditioned explains why it otherwise is not)."""
     nb: Dict[str, torch.Tensor] = OrderedDict()
-    pool = lambda t: F.max_pool2d(t, 2)
-    e1 = _conv_block(x, params, bufs, "enc1", training, nb, taps)
-    e2 = _conv_block(pool(e1), params, bufs, "enc2", training, nb, taps)
-    e3 = _conv_block(pool(e2), params, bufs, "enc3", training, nb, taps)
-    e4 = _conv_block(pool(e3), params, bufs, "enc4", training, nb, taps)
-    bt = _conv_block(pool(e4), params, bufs, "bottleneck", training, nb, taps)
+
+    def make_pool(blk):
+        if forced is None:
+            return lambda t: F.max_pool2d(t, 2)
+        idx = forced[f"{blk}.pool_idx"]
+        return lambda t: torch.gather(t.flatten(2), 2, idx.flatten(2)).view(idx.shape)
+
+    cb = lambda t, name: _conv_block(t, params, bufs, name, training, nb, taps, forced)
+    e1 = cb(x, "enc1")
+    e2 = cb(make_pool("enc1")(e1), "enc2")
+    e3 = cb(make_pool("enc2")(e2), "enc3")
+    e4 = cb(make_pool("enc3")(e3), "enc4")
+    bt = cb(make_pool("enc4")(e4), "bottleneck")
     d = bt
     for k, skip in ((4, e4), (3, e3), (2, e2), (1, e1)):
         up = _upconv(d, params[f"upconv{k}.weight"], params[f"upconv{k}.bias"])
         if taps is not None:
             taps[f"upconv{k}"] = up
-        d = _conv_block(torch.cat([up, skip], dim=1), params, bufs, f"dec{k}", training, nb, taps)
+        d = cb(torch.cat([up, skip], dim=1), f"dec{k}")
     logits = F.conv2d(d, params["out.weight"], params["out.bias"])
     return logits, nb
 
@@ -248,11 +277,11 @@ def loss_and_grads(params, bufs, x, target, training=True):
     return loss.detach(), logits.detach(), OrderedDict(zip(p.keys(), grads)), nb
 
 
-def grads_from_dlogits(params, bufs, x, dlogits, training=True):
+def grads_from_dlogits(params, bufs, x, dlogits, training=True, forced=None):
     """Backward of the UNet alone for a given upstream gradient (what the
     drop-in's autograd.Function.backward must reproduce)."""
     p = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in params.items())
-    logits, nb = forward(p, bufs, x, training)
+    logits, nb = forward(p, bufs, x, training, forced=forced)
     grads = torch.autograd.grad(logits, list(p.values()), grad_outputs=dlogits)
     return logits.detach(), OrderedDict(zip(p.keys(), grads)), nb
 
