@@ -46,22 +46,29 @@ class GradBuckets:
         if cur_end > start:
             self.buckets.append((start, cur_end, order[-1]))
         self.trigger = {last: i for i, (_, _, last) in enumerate(self.buckets)}
-        self.stream = torch.cuda.Stream()
+        self.on_gpu = engine.flat_grad.is_cuda
+        self.stream = torch.cuda.Stream() if self.on_gpu else None
         self.pending = []
         engine.grad_ready = self.on_ready
+
+    def _reduce(self, s, e):
+        sl = self.eng.flat_grad[s:e]
+        dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
+        sl.mul_(1.0 / self.world)
 
     def on_ready(self, name: str):
         i = self.trigger.get(name)
         if i is None:
             return
         s, e, _ = self.buckets[i]
+        if not self.on_gpu:                      # gloo / CPU tensors: synchronous
+            self._reduce(s, e)
+            return
         ev = torch.cuda.Event()
         ev.record()                              # gradients of this bucket are enqueued up to here
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
-            sl = self.eng.flat_grad[s:e]
-            dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
-            sl.mul_(1.0 / self.world)
+            self._reduce(s, e)
         done = torch.cuda.Event()
         done.record(self.stream)
         self.pending.append(done)

@@ -1,0 +1,64 @@
+"""Multi-rank path on CPU (gloo, world_size 2): the bucketed gradient
+all-reduce must leave, on every rank, the mean of the per-rank gradients in
+every parameter's slice of the flat buffer."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fea_amd
+        from fea_amd.engine import UNetEngine, param_order
+        from fea_amd.train import GradBuckets
+        torch.manual_seed(0)
+        m = fea_amd.FloorPlanSegmentationModel()
+        eng = UNetEngine(m, torch.float32)
+        eng._ensure_flat_grad()
+        bk = GradBuckets(eng, bucket_mb=16.0)
+        assert len(bk.buckets) >= 3
+        assert bk.buckets[0][0] == 0 and bk.buckets[-1][1] == eng.flat_grad.numel()
+        for (s0, e0, _), (s1, _, _) in zip(bk.buckets, bk.buckets[1:]):
+            assert e0 == s1
+        g = torch.Generator().manual_seed(100 + rank)
+        for n in param_order(m):
+            eng.grad_views[n].copy_(torch.randn(eng.grad_views[n].shape, generator=g))
+        mine = eng.flat_grad.clone()
+        # "backward": report every parameter in the order backward finishes them
+        for n in param_order(m):
+            eng.grad_ready(n)
+        bk.wait()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        mean = sum(gathered) / world
+        ok = torch.allclose(eng.flat_grad, mean, rtol=1e-6, atol=1e-7)
+        q.put((rank, bool(ok), len(bk.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res

@@ -1,0 +1,200 @@
+"""End-to-end parity of the HIP UNet (through the drop-in nn.Module, hence
+through the C ABI) against the CPU oracle and the reference's golden digests.
+
+Stated tolerances (north_star):
+  fp32 path : forward and backward within 1e-4 relative.  Gradients are
+              compared with the ReLU masks / pool arg-max pinned to the HIP
+              run's decisions (oracle `forced=`): the network's gradient is
+              discontinuous at those kinks and two fp32 implementations differ
+              there by ~1/sqrt(numel) (see oracle/make_golden.py).
+  bf16 path : logits within 3e-2 L2-relative; gradients (kinks pinned) within
+              1.5e-1 worst layer / 5e-2 median layer at random init on tiny
+              batches (bf16 storage of every activation through 23 layers, BN
+              over as few as 8 samples).
+  masks/IoU : bit-exact given identical logits.
+"""
+import pytest
+import torch
+
+import fea_amd
+from fea_amd import functional as Fn
+from fea_amd.train import UNetTrainer
+from oracle import unet_oracle as O
+from tests.helpers import digest_err, load_golden, max_rel, rel_l2
+from tests.test_oracle_golden import case_inputs
+
+pytestmark = pytest.mark.gpu
+GOLD = load_golden()
+
+
+def cancelled(k):
+    p = k.split(".")
+    return len(p) == 3 and p[1] in ("0", "3") and p[2] == "bias"
+
+
+def make(seed, dt, **kw):
+    torch.manual_seed(seed)
+    m = fea_amd.FloorPlanSegmentationModel(compute_dtype=dt, **kw).cuda()
+    params, bufs = O.split_state({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    return m, params, bufs
+
+
+def run_hip(m, x, dl):
+    taps = {}
+    m._engine().debug_taps = taps
+    m.zero_grad()
+    lg = m(x.cuda())
+    lg.backward(dl.cuda())
+    torch.cuda.synchronize()
+    m._engine().debug_taps = None
+    return lg.detach().cpu(), {k: v.cpu() for k, v in taps.items()}
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32), (1, 64, 48), (3, 16, 16)])
+def test_fp32_forward_backward_buffers(shape):
+    n, h, w = shape
+    m, params, bufs = make(10, "fp32")
+    m.train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 3, h, w, generator=g)
+    dl = torch.randn(n, 6, h, w, generator=g) / (n * h * w)
+    lg, taps = run_hip(m, x, dl)
+    forced = O.forced_from_taps(taps)
+    lo, go, nb = O.grads_from_dlogits(params, bufs, x, dl, forced=forced)
+    lo_free, _ = O.forward(params, bufs, x, True)
+    assert rel_l2(lg, lo_free) < 1e-4 and max_rel(lg, lo_free) < 1e-4
+    for k, p in m.named_parameters():
+        if cancelled(k):
+            # mathematically zero (BN cancels the conv bias): both sides are rounding noise
+            scale = go[k.replace(".bias", ".weight")].abs().max().item()
+            assert p.grad.abs().max().item() < 1e-3 * scale + 1e-7, k
+        else:
+            assert rel_l2(p.grad, go[k]) < 1e-4, (k, rel_l2(p.grad, go[k]))
+    for k, b in m.named_buffers():
+        if k.endswith("num_batches_tracked"):
+            assert int(b) == 1
+        else:
+            assert rel_l2(b, nb[k]) < 1e-4, k
+    # eval mode uses the running statistics just updated
+    m.eval()
+    with torch.no_grad():
+        le = m(x.cuda()).cpu()
+    bufs2 = {k: v.detach().cpu() for k, v in m.named_buffers()}
+    lo_e, _ = O.forward(params, bufs2, x, False)
+    assert rel_l2(le, lo_e) < 1e-4 and max_rel(le, lo_e) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32), (4, 64, 64)])
+def test_bf16_forward_backward(shape):
+    n, h, w = shape
+    m, params, bufs = make(11, "bf16")
+    m.train()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(n, 3, h, w, generator=g)
+    dl = torch.randn(n, 6, h, w, generator=g) / (n * h * w)
+    lg, taps = run_hip(m, x, dl)
+    lo, go, nb = O.grads_from_dlogits(params, bufs, x, dl, forced=O.forced_from_taps(taps))
+    assert rel_l2(lg, lo) < 3e-2
+    errs = sorted(rel_l2(p.grad, go[k]) for k, p in m.named_parameters() if not cancelled(k))
+    assert errs[-1] < 1.5e-1 and errs[len(errs) // 2] < 5e-2, (errs[-1], errs[len(errs) // 2])
+    for k, b in m.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            assert rel_l2(b, nb[k]) < 3e-2, k
+
+
+@pytest.mark.parametrize("name", ["train_32", "train_c1", "plan_64"])
+def test_against_reference_golden_digests(name):
+    """HIP fp32 path against digests of the REFERENCE module's own outputs."""
+    case = GOLD[name]
+    torch.manual_seed(case["seed"])
+    m = fea_amd.FloorPlanSegmentationModel(in_channels=case["in_channels"], num_classes=case["num_classes"],
+                                           compute_dtype="fp32").cuda().train()
+    x, tgt = case_inputs(case)
+    rec = case["train"][0]
+    logits = m(x.cuda())
+    loss = Fn.bce_dice_loss(logits, tgt.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert digest_err(rec["logits"], logits.detach().cpu()) < 1e-4
+    assert abs(loss.item() - rec["loss"]) < 1e-4 * abs(rec["loss"])
+    for k, p in m.named_parameters():
+        if not cancelled(k):
+            # unpinned kinks: strict cases carry no flip between the reference and
+            # the oracle, but HIP rounding differs again -> loose bound here, the
+            # strict 1e-4 gradient check is test_fp32_forward_backward_buffers
+            assert digest_err(rec["grads"][k], p.grad.cpu()) < 5e-2, k
+    for k, b in m.named_buffers():
+        assert digest_err(rec["buffers"][k], b.float().cpu()) < 1e-4, k
+
+
+def test_config1_eval_forward_matches_reference():
+    case = GOLD["config1"]
+    torch.manual_seed(0)
+    m = fea_amd.FloorPlanSegmentationModel(compute_dtype="fp32").cuda().eval()
+    x, tgt = O.synthetic_batch(1, 256, 256, seed=4321)
+    with torch.no_grad():
+        y = m(x.cuda())
+    assert digest_err(case["logits"], y.cpu()) < 1e-4
+    mask, inter, union = Fn.mask_iou_counts(y, tgt.cuda())
+    pm, pi, pu = O.mask_iou_counts(y.cpu(), tgt)
+    assert torch.equal(mask.cpu(), pm) and torch.equal(inter.cpu(), pi) and torch.equal(union.cpu(), pu)
+    assert abs(int(mask.sum()) - case["pred_sum"]) <= 4
+
+
+def test_training_steps_track_the_oracle():
+    """Three optimizer steps (fwd, BCE+Dice, bwd, clip 1.0, AdamW) in fp32."""
+    m, params, bufs = make(12, "fp32")
+    tr = UNetTrainer(m)
+    x, tgt = O.synthetic_batch(2, 32, 32, seed=99)
+    g = torch.Generator().manual_seed(3)
+    x = x + 0.1 * torch.randn(x.shape, generator=g)
+    state = {}
+    for step in range(3):
+        loss = tr.step(x.cuda(), tgt.cuda())
+        lo, _, grads, nb = O.loss_and_grads(params, bufs, x, tgt, training=True)
+        clipped, norm = O.clip_grad_norm(grads, 1.0)
+        params = O.adamw_step(params, clipped, state)
+        bufs = nb
+        assert abs(loss.item() - lo.item()) < 2e-3 * abs(lo.item()), (step, loss.item(), lo.item())
+        assert abs(tr.last_grad_norm.item() - norm.item()) < 5e-2 * norm.item()
+    worst = max(rel_l2(p.detach(), params[k]) for k, p in m.named_parameters() if not cancelled(k))
+    assert worst < 5e-3, worst
+
+
+def test_module_contract_on_device():
+    m = fea_amd.FloorPlanSegmentationModel(compute_dtype="fp32").cuda().train()
+    x = torch.randn(2, 3, 32, 32, device="cuda")
+    with pytest.raises(RuntimeError):
+        m(torch.randn(1, 3, 24, 24, device="cuda"))         # not a multiple of 16 (reference fails too)
+    with pytest.raises(ValueError):
+        m(torch.randn(1, 4, 32, 32, device="cuda"))
+    y = m(x)
+    assert y.shape == (2, 6, 32, 32) and y.dtype == torch.float32 and y.requires_grad
+    # non-contiguous input, and gradient accumulation over two backward calls
+    xt = torch.randn(2, 32, 32, 3, device="cuda").permute(0, 3, 1, 2)
+    m.zero_grad()
+    m(xt).sum().backward()
+    g1 = m.out.weight.grad.clone()
+    m(xt).sum().backward()
+    assert torch.allclose(m.out.weight.grad, 2 * g1, rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        assert not m(x).requires_grad
+    # a downstream torch consumer (the reference pipeline feeds the logits to a
+    # Conv2d(6, 64, ...), models.py:91): gradients flow through our node
+    head = torch.nn.Conv2d(6, 8, 3, padding=1).cuda()
+    m.zero_grad()
+    head(m(x)).square().mean().backward()
+    assert m.enc1[0].weight.grad is not None and torch.isfinite(m.enc1[0].weight.grad).all()
+    assert m.enc1[0].weight.grad.abs().sum() > 0
+
+
+def test_loss_autograd_and_iou():
+    x = torch.randn(2, 6, 32, 32)
+    t = (torch.rand(2, 6, 32, 32) < 0.2).to(torch.uint8)
+    xr = x.clone().requires_grad_(True)
+    O.bce_dice_loss(xr, t).backward()
+    xd = x.cuda().requires_grad_(True)
+    loss = Fn.bce_dice_loss(xd, t.cuda())
+    (2 * loss).backward()
+    assert rel_l2(xd.grad.cpu(), 2 * xr.grad) < 1e-4
+    assert torch.equal(Fn.binarise_mask(torch.arange(256, dtype=torch.uint8).cuda()).cpu(), O.binarise_mask(torch.arange(256, dtype=torch.uint8)))
