@@ -154,6 +154,13 @@ class UNetEngine:
         # parameter's gradient have been enqueued (used for overlapped all-reduce)
         self.grad_ready: Optional[Callable[[str], None]] = None
         self.debug_taps: Optional[dict] = None
+        # Packed-weight cache generation.  Parameter._version is NOT bumped by
+        # fused optimizers (torch._fused_adamw_), so in training mode every
+        # forward starts a new generation (weights are re-packed once per step,
+        # ~31 M elements: negligible); eval-mode forwards reuse the packs until
+        # the module leaves eval mode, a parameter's version/storage changes or
+        # invalidate() is called.
+        self._gen = 0
         L.load()
 
     # ------------------------------------------------------------------ utils
@@ -201,16 +208,20 @@ class UNetEngine:
 
     # -------------------------------------------------------------- packing
     def _pack(self, key: str, param: torch.nn.Parameter, numel: int, fn: str, *args):
-        ver = param._version
+        ver = (self._gen, param._version, param.data_ptr())
         buf = self.packed.get(key)
         if buf is None:
             buf = torch.empty(numel, dtype=self.dtype, device=self.device)
             self.packed[key] = buf
             self.packed_ver[key] = -1
-        if self.packed_ver[key] != (ver, param.data_ptr()):
+        if self.packed_ver[key] != ver:
             L.call(fn, param.detach(), buf, *args, self.code, L.stream_ptr())
-            self.packed_ver[key] = (ver, param.data_ptr())
+            self.packed_ver[key] = ver
         return buf
+
+    def invalidate(self):
+        """Forget packed weights (call after parameters were changed in place)."""
+        self._gen += 1
 
     def _w_fwd(self, name: str):
         p = self._params()[name + ".weight"]
@@ -240,6 +251,8 @@ class UNetEngine:
             # the reference fails at the first torch.cat for such sizes
             raise RuntimeError(f"Sizes of tensors must match: H and W must be multiples of 16, got {H}x{W}")
         self._ensure_device(x)
+        if training:
+            self._gen += 1
         x = x.detach().contiguous().float()
         pl = self.plan(N, H, W)
         P, B = self._params(), self._bufs()

@@ -109,6 +109,14 @@ class FloorPlanSegmentationModel(nn.Module):
             self.__dict__["_eng"] = eng
         return eng
 
+    def train(self, mode: bool = True):
+        # leaving / entering eval mode: packed weights may be stale (fused
+        # optimizers do not bump Parameter._version)
+        eng = self.__dict__.get("_eng")
+        if eng is not None:
+            eng.invalidate()
+        return super().train(mode)
+
     def set_compute_dtype(self, compute_dtype):
         self.compute_dtype = _resolve_dtype(compute_dtype)
         return self

@@ -157,8 +157,14 @@ def test_training_steps_track_the_oracle():
         bufs = nb
         assert abs(loss.item() - lo.item()) < 2e-3 * abs(lo.item()), (step, loss.item(), lo.item())
         assert abs(tr.last_grad_norm.item() - norm.item()) < 5e-2 * norm.item()
-    worst = max(rel_l2(p.detach(), params[k]) for k, p in m.named_parameters() if not cancelled(k))
-    assert worst < 5e-3, worst
+    # Adam steps are +-lr-sized and sign-like for tiny gradients, so individual
+    # elements (notably BN betas, which start at 0) can differ by O(lr) after a
+    # kink flip: weights are compared in norm, everything by an absolute bound.
+    for k, p in m.named_parameters():
+        d = (p.detach().cpu() - params[k]).abs().max().item()
+        assert d <= 2.1e-4 * 3, (k, d)
+        if p.dim() > 1:
+            assert rel_l2(p.detach(), params[k]) < 2e-3, (k, rel_l2(p.detach(), params[k]))
 
 
 def test_module_contract_on_device():
