@@ -1,0 +1,344 @@
+// conv3x3 weight gradient, bf16, LDS-DMA pipelined (gfx950).
+//
+//   dW[co][ci][tap] = sum_p dy[p][co] * x[p + tap][ci]        (models.py:28,31 backward)
+//
+// Same math and LDS image as wgrad.hip MODE 0 (P = dy tile, Q = x halo tile,
+// both [pixel][64 ch] 128-byte rows read with ds_read_b64_tr_b16), restructured
+// so that the matrix pipe never waits for staging:
+//   * one 512-thread workgroup per CU owns a 64(co) x 64(ci) x 9 output tile and
+//     walks a range of 256-pixel tiles; the two wave groups (waves 0-3 / 4-7)
+//     take alternate tile rows (a split of the reduction inside the workgroup,
+//     two waves per SIMD for latency hiding);
+//   * tiles are staged by global_load_lds (16 B per lane, no VGPR round trip)
+//     into a two-stage LDS ring: the loads of tile t+1 are in flight while
+//     tile t is multiplied; one barrier per tile.  The XOR swizzle is applied
+//     on the per-lane SOURCE address (the LDS-DMA destination is lane-linear);
+//     out-of-image halo rows read from a zero line.
+//   * epilogue: the two groups are summed through LDS and the tile is written
+//     in the parameter's own OIHW order ([co][ci][9], 16-byte stores), so the
+//     cross-workgroup reduction is a plain vector sum.
+#include "common.h"
+#include <type_traits>
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+__device__ __attribute__((aligned(128))) const uint32_t fea_zero_line[32] = {0};
+
+struct Wgrad2Args {
+    const __bf16* p; const __bf16* q; float* out;     // out: slab [split][M][Nn][9] (or dW itself when splits == 1)
+    long long p_img_stride, q_img_stride, out_split_stride;
+    int ldp, ldq;
+    int H, W;
+    int M, Nn;
+    int tiles_x, tiles_y, ntiles, tiles_per_split;
+    int nmt, nnt;
+};
+
+__device__ __forceinline__ int swzw2(int x) {      // bit-reverse of bits 1..3 of x (as wgrad.hip)
+    const int u = (x >> 1) & 7;
+    return ((u & 1) << 2) | (u & 2) | (u >> 2);
+}
+
+// Issue the LDS-DMA loads of one 256-pixel tile (P rows then Q halo rows) into `sb`.
+template <int TWS>
+__device__ __forceinline__ void wg2_issue(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
+                                          const int (&pdesc)[4], const int (&qdesc)[6], int wave, int tile, char* sb) {
+    constexpr int TW = 1 << TWS, TH = 256 / TW;
+    constexpr int QROWS = 352, PBYTES = 256 * 128;
+    const int H = g.H, W = g.W;
+    int tt = tile;
+    const int tile_x = tt % g.tiles_x; tt /= g.tiles_x;
+    const int tile_y = tt % g.tiles_y;
+    const int n_img = tt / g.tiles_y;
+    const int y0 = tile_y * TH, x0 = tile_x * TW;
+    const __bf16* pimg = pg + (long long)n_img * g.p_img_stride;
+    const __bf16* qimg = qg + (long long)n_img * g.q_img_stride;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int d = pdesc[it];
+        const int gy = y0 + (d & 0xff) - 1, gx = x0 + ((d >> 8) & 0xff) - 1;
+        const bool ok = gy < H && gx < W;
+        const __bf16* src = ok ? pimg + (long long)(gy * W + gx) * g.ldp + (d >> 24) * 8
+                               : reinterpret_cast<const __bf16*>(fea_zero_line);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sb + (it * 8 + wave) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        if (it * 8 + wave < QROWS / 8) {
+            const int d = qdesc[it];
+            const int gy = y0 + (d & 0xff) - 1, gx = x0 + ((d >> 8) & 0xff) - 1;
+            const bool ok = !((d >> 16) & 1) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const __bf16* src = ok ? qimg + (long long)(gy * W + gx) * g.ldq + (d >> 24) * 8
+                                   : reinterpret_cast<const __bf16*>(fea_zero_line);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sb + PBYTES + (it * 8 + wave) * 1024), 16, 0, 0);
+        }
+    }
+}
+
+// compile-time unrolled loop: f(std::integral_constant<int, I>) for I in [0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+
+// Transposing LDS read issued as inline asm: hipcc neither reorders it nor
+// waits for it -- the waits are the counted s_waitcnt of wg2_wait below.
+template <int OFF>
+__device__ __forceinline__ void lds_tr(u32x2& dst, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+// s_waitcnt lgkmcnt(N), tied to the fragments it retires so that the MFMA that
+// consumes them cannot be hoisted above it.
+template <int N>
+__device__ __forceinline__ void wg2_wait(u32x2& a0, u32x2& a1, u32x2& b0, u32x2& b1) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void wg2_wait(u32x2& b0, u32x2& b1) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(N));
+}
+
+template <int NT> struct Wg2Frag { u32x2 a[2]; u32x2 b[NT][2]; };
+
+// reads issued after MFMA t of a step (the NRD = 2 + 2 NT reads of the NEXT step)
+template <int NT> __device__ constexpr int wg2_cnt(int t) { return (2 + 2 * NT + NT - 1 - t) / NT; }
+template <int NT> __device__ constexpr int wg2_start(int t) { int s = 0; for (int u = 0; u < t; ++u) s += wg2_cnt<NT>(u); return s; }
+
+// read number R (0,1 = A halves; 2+2t, 3+2t = B halves of tap t) of k-step S
+template <int TWS, int TAP0, int NT, int S, int R>
+__device__ __forceinline__ void wg2_read(Wg2Frag<NT>& f, const uint32_t (&pa)[(1 << TWS) / 16][2],
+                                         const uint32_t (&qa)[(1 << TWS) / 16][2][3]) {
+    constexpr int TW = 1 << TWS, HW2 = TW + 2, XSEG = TW / 16;
+    constexpr int ty = S / XSEG, xs = S % XSEG;
+    if constexpr (R < 2) {
+        lds_tr<ty * TW * 128>(f.a[R], pa[xs][R]);
+    } else {
+        constexpr int t = (R - 2) / 2, hf = (R - 2) % 2, tap = TAP0 + t, dy = tap / 3, dx = tap % 3;
+        lds_tr<(ty + dy) * HW2 * 128>(f.b[t][hf], qa[xs][hf][dx]);
+    }
+}
+
+template <int TWS, int TAP0, int NT, int S>
+__device__ __forceinline__ void wg2_kstep(Wg2Frag<NT>& cur, Wg2Frag<NT>& nxt, const uint32_t (&pa)[(1 << TWS) / 16][2],
+                                          const uint32_t (&qa)[(1 << TWS) / 16][2][3], f32x16 (&acc)[NT]) {
+    constexpr int NSTEP = 256 / 16, NRD = 2 + 2 * NT;
+    constexpr bool more = S + 1 < NSTEP;
+    sfor<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int issued = more ? wg2_start<NT>(t) : 0;          // next-step reads issued so far
+        if constexpr (t == 0) wg2_wait<NRD - 4 + issued>(cur.a[0], cur.a[1], cur.b[0][0], cur.b[0][1]);
+        else                  wg2_wait<NRD - (4 + 2 * t) + issued>(cur.b[t][0], cur.b[t][1]);
+        const u32x4 af = {cur.a[0].x, cur.a[0].y, cur.a[1].x, cur.a[1].y};
+        const u32x4 bf = {cur.b[t][0].x, cur.b[t][0].y, cur.b[t][1].x, cur.b[t][1].y};
+        mma16(acc[t], af, bf, (const __bf16*)nullptr);
+        if constexpr (more) {
+            sfor<0, wg2_cnt<NT>(t)>([&](auto rc) {
+                wg2_read<TWS, TAP0, NT, S + 1, wg2_start<NT>(t) + decltype(rc)::value>(nxt, pa, qa);
+            });
+        }
+    });
+    if constexpr (more) wg2_kstep<TWS, TAP0, NT, S + 1>(nxt, cur, pa, qa, acc);
+}
+
+// One pipeline step: start the LDS-DMA loads of `next_tile` into the other
+// stage, then multiply the tile resident at LDS byte address `rd` for taps
+// TAP0 .. TAP0+NT-1.  The sixteen 16-pixel k-steps are fully unrolled and
+// software-pipelined by hand: the fragments of step s+1 are read from LDS
+// (inline asm) between the MFMAs of step s and retired by counted lgkmcnt.
+template <int TWS, int TAP0, int NT>
+__device__ __forceinline__ void wg2_step(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
+                                         const int (&pdesc)[4], const int (&qdesc)[6], int wave, int next_tile,
+                                         char* dma, uint32_t rd,
+                                         const int (&pcol)[(1 << TWS) / 16][2], const int (&qcol)[(1 << TWS) / 16][2][3],
+                                         f32x16 (&acc)[NT]) {
+    constexpr int XSEG = (1 << TWS) / 16, PBYTES = 256 * 128;
+    if (next_tile >= 0) wg2_issue<TWS>(g, pg, qg, pdesc, qdesc, wave, next_tile, dma);
+    uint32_t pa[XSEG][2], qa[XSEG][2][3];
+#pragma unroll
+    for (int xs = 0; xs < XSEG; ++xs)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            pa[xs][t] = rd + pcol[xs][t];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) qa[xs][t][dx] = rd + PBYTES + qcol[xs][t][dx];
+        }
+    Wg2Frag<NT> f0, f1;
+    sfor<0, 2 + 2 * NT>([&](auto rc) { wg2_read<TWS, TAP0, NT, 0, decltype(rc)::value>(f0, pa, qa); });
+    wg2_kstep<TWS, TAP0, NT, 0>(f0, f1, pa, qa, acc);
+}
+
+// Tile loop + epilogue staging for one wave group (taps TAP0 .. TAP0+NT-1).
+template <int TWS, int TAP0, int NT>
+__device__ __forceinline__ void wg2_run(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
+                                        const int (&pdesc)[4], const int (&qdesc)[6], int wave, int t_begin, int t_end,
+                                        char* smem, const int (&pcol)[(1 << TWS) / 16][2], const int (&qcol)[(1 << TWS) / 16][2][3],
+                                        int orow, int ocol, int h) {
+    constexpr int STAGE = (256 + 352) * 128;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int stage = (tile - t_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // this wave's LDS-DMA has landed; barrier: tile complete, other stage free
+        wg2_step<TWS, TAP0, NT>(g, pg, qg, pdesc, qdesc, wave, tile + 1 < t_end ? tile + 1 : -1,
+                                smem + (stage ^ 1) * STAGE, lds_base + stage * STAGE, pcol, qcol, acc);
+    }
+    __syncthreads();                     // every wave is done reading the stages
+    float* ot = reinterpret_cast<float*>(smem);       // [64 m][64 n][9]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int mr = orow + (e & 3) + 8 * (e >> 2) + 4 * h;
+            ot[(mr * 64 + ocol) * 9 + TAP0 + t] = acc[t][e];
+        }
+}
+
+template <int TWS>
+__global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args g) {
+    constexpr int TW = 1 << TWS, TH = 256 / TW, HW2 = TW + 2;
+    constexpr int QROWS = 352;                       // >= (TH+2)*HW2 (340 / 324), multiple of 8
+    constexpr int PBYTES = 256 * 128, QBYTES = QROWS * 128, STAGE = PBYTES + QBYTES;
+    constexpr int NPI = 4, NQI = 6;                  // glds wave-instructions per wave: P rows 0..255, Q rows 0..351
+    constexpr int XSEG = TW / 16;
+    __shared__ __attribute__((aligned(128))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = wave >> 2;                        // tap group
+    const int wa = (wave >> 1) & 1, wb = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntp = g.nmt * g.nnt;
+    const int tp = lid % ntp, split = lid / ntp;
+    const int m0 = (tp / g.nnt) * 64, n0 = (tp % g.nnt) * 64;
+    const int H = g.H, W = g.W;
+
+    // ---- fragment offsets (identical to wgrad.hip) -------------------------
+    int pcol[XSEG][2], qcol[XSEG][2][3];
+    {
+        const int gi = lane >> 4, li = lane & 15;
+        const int chl = 16 * (gi & 1) + 4 * (li & 3);
+        const int qrow = li >> 2;
+#pragma unroll
+        for (int xs = 0; xs < XSEG; ++xs)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int x = xs * 16 + 8 * h + 4 * t + qrow;
+                const int chp = wa * 32 + chl, chq = wb * 32 + chl;
+                pcol[xs][t] = x * 128 + ((((chp >> 3) ^ swzw2(x))) << 4) + (chp & 7) * 2;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int hx = x + dx;
+                    qcol[xs][t][dx] = hx * 128 + ((((chq >> 3) ^ swzw2(hx))) << 4) + (chq & 7) * 2;
+                }
+            }
+    }
+
+    // ---- LDS-DMA descriptors: instruction it of this wave moves 8 rows ------
+    // packed: (ry+1) | (rx+1) << 8 | invalid << 16 | source chunk << 24
+    int pdesc[NPI], qdesc[NQI];
+    {
+        const int rsub = lane >> 3, cpos = lane & 7;
+#pragma unroll
+        for (int it = 0; it < NPI; ++it) {
+            const int row = (it * 8 + wave) * 8 + rsub;
+            const int ty = row >> TWS, tx = row & (TW - 1);
+            pdesc[it] = (ty + 1) | ((tx + 1) << 8) | ((cpos ^ swzw2(tx)) << 24);
+        }
+#pragma unroll
+        for (int it = 0; it < NQI; ++it) {
+            const int row = (it * 8 + wave) * 8 + rsub;
+            const int hy = row / HW2, hx = row - hy * HW2;
+            const int inval = hy >= TH + 2 ? 1 : 0;
+            qdesc[it] = hy | (hx << 8) | (inval << 16) | ((cpos ^ swzw2(hx)) << 24);   // ry = hy-1, rx = hx-1
+        }
+    }
+
+    const __bf16* __restrict__ pg = g.p + m0;
+    const __bf16* __restrict__ qg = g.q + n0;
+    const int t_begin = split * g.tiles_per_split;
+    const int t_end = min(t_begin + g.tiles_per_split, g.ntiles);
+
+    if (t_begin < t_end) wg2_issue<TWS>(g, pg, qg, pdesc, qdesc, wave, t_begin, smem);
+    // waves 0-3 take taps 0..4, waves 4-7 taps 5..8: every SIMD hosts one wave of each group
+    if (kg == 0) wg2_run<TWS, 0, 5>(g, pg, qg, pdesc, qdesc, wave, t_begin, t_end, smem, pcol, qcol, wa * 32, wb * 32 + r, h);
+    else         wg2_run<TWS, 5, 4>(g, pg, qg, pdesc, qdesc, wave, t_begin, t_end, smem, pcol, qcol, wa * 32, wb * 32 + r, h);
+    __syncthreads();
+    const float* ot = reinterpret_cast<const float*>(smem);
+    float* dst = g.out + (long long)split * g.out_split_stride + ((long long)m0 * g.Nn + n0) * 9;
+    // 64 rows x 576 floats; 144 float4 per row
+    for (int i = tid; i < 64 * 144; i += 512) {
+        const int row = i / 144, c4 = i - row * 144;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * 576 + c4 * 4);
+        *reinterpret_cast<f32x4*>(dst + (long long)row * g.Nn * 9 + c4 * 4) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                            int splits, long long per4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per4) return;
+    const f32x4* s = reinterpret_cast<const f32x4*>(slab);
+    f32x4 a = s[i];
+    for (int sp = 1; sp < splits; ++sp) a += s[sp * per4 + i];
+    reinterpret_cast<f32x4*>(out)[i] = a;
+}
+
+// ---------------------------------------------------------------------------
+struct Wgrad2Plan { int tws, tiles_x, tiles_y, ntiles, splits, tiles_per_split, nmt, nnt; };
+
+static Wgrad2Plan wgrad2_plan(int N, int H, int W, int M, int Nn) {
+    Wgrad2Plan p;
+    p.tws = W >= 32 ? 5 : 4;
+    const int TW = 1 << p.tws, TH = 256 / TW;
+    p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH;
+    p.ntiles = N * p.tiles_x * p.tiles_y;
+    p.nmt = M / 64; p.nnt = Nn / 64;
+    int want = 1024 / (p.nmt * p.nnt);               // ~4 workgroups per CU over the launch
+    if (want < 1) want = 1;
+    if (want > p.ntiles) want = p.ntiles;
+    p.tiles_per_split = (p.ntiles + want - 1) / want;
+    p.splits = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
+    return p;
+}
+
+size_t fea_wgrad2_ws_bytes(int N, int H, int W, int Cm, int Cn) {
+    Wgrad2Plan p = wgrad2_plan(N, H, W, Cm, Cn);
+    return p.splits > 1 ? (size_t)p.splits * 9 * Cm * Cn * sizeof(float) : 0;
+}
+
+// bf16 conv3x3 wgrad; arguments already validated by the caller (wgrad.hip)
+int fea_wgrad2_launch(const void* dy, int lddy, const void* x, int ldx, float* dW, void* ws, size_t ws_bytes,
+                      int N, int H, int W, int Cin, int Cout, hipStream_t s) {
+    const int M = Cout, Nn = Cin;
+    Wgrad2Plan p = wgrad2_plan(N, H, W, M, Nn);
+    const size_t need = p.splits > 1 ? (size_t)p.splits * 9 * M * Nn * sizeof(float) : 0;
+    FEA_CHECK(ws_bytes >= need, FEA_E_WORKSPACE, "fea_conv3x3_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+    FEA_CHECK(((uintptr_t)dW % 16 == 0) && ((uintptr_t)ws % 16 == 0), FEA_E_BADARG, "fea_conv3x3_wgrad: dW/ws must be 16-byte aligned");
+    Wgrad2Args a{};
+    a.p = (const __bf16*)dy; a.q = (const __bf16*)x;
+    a.out = p.splits > 1 ? (float*)ws : dW;
+    a.out_split_stride = (long long)9 * M * Nn;
+    a.p_img_stride = (long long)H * W * lddy; a.q_img_stride = (long long)H * W * ldx;
+    a.ldp = lddy; a.ldq = ldx; a.H = H; a.W = W; a.M = M; a.Nn = Nn;
+    a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
+    a.nmt = p.nmt; a.nnt = p.nnt;
+    dim3 grid((unsigned)(p.nmt * p.nnt * p.splits)), block(512);
+    if (p.tws == 5) hipLaunchKernelGGL((wgrad2_kernel<5>), grid, block, 0, s, a);
+    else            hipLaunchKernelGGL((wgrad2_kernel<4>), grid, block, 0, s, a);
+    FEA_LAUNCH_CHECK();
+    if (p.splits > 1) {
+        const long long per4 = (long long)9 * M * Nn / 4;
+        hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3((unsigned)((per4 + 255) / 256)), dim3(256), 0, s,
+                           (const float*)ws, dW, p.splits, per4);
+        FEA_LAUNCH_CHECK();
+    }
+    return FEA_OK;
+}
