@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 #include "../../include/fea_unet.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -47,6 +48,12 @@ template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// compile-time unrolled loop: f(std::integral_constant<int, I>) for I in [0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
 }
 
 // host side -----------------------------------------------------------------

@@ -170,27 +170,73 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
             *reinterpret_cast<u32x4*>(ldsW + buf * W_BYTES + row * 128 + ((sc ^ swz(row)) << 4)) = v[j];
         }
     };
+    // One tap (or one gathered k-chunk): 4 k-steps of 16.  bf16: the LDS reads
+    // are inline asm, software-pipelined one k-step ahead of the MFMAs and
+    // retired by counted lgkmcnt (hipcc otherwise schedules each read right in
+    // front of its first use and exposes the LDS latency every k-step).
+    const uint32_t lds_a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ldsA;
+    const uint32_t lds_w0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ldsW;
     auto compute = [&](int row_shift, int buf) {
-        int abase[MT], aswz[MT];
+        if constexpr (sizeof(T) == 2) {
+            constexpr int NRD = MT + 2, NMF = 2 * MT;
+            uint32_t aa[MT], ba[2];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int row = a_row[m] + row_shift;
-            abase[m] = row * 128;
-            aswz[m] = swz(row);
-        }
-        const char* wb = ldsW + buf * W_BYTES;
+            for (int m = 0; m < MT; ++m) {
+                const int row = a_row[m] + row_shift;
+                aa[m] = lds_a0 + row * 128 + ((h ^ swz(row)) << 4);
+            }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int c = 2 * ks + h;
-            u32x4 af[MT], bf[2];
+            for (int nt = 0; nt < 2; ++nt) ba[nt] = lds_w0 + buf * W_BYTES + b_addr[nt] + ((h ^ b_swz[nt]) << 4);
+            u32x4 fr[2][NRD];                      // [0,1] = B, [2..] = A
+            auto rd = [&](u32x4& dst, uint32_t addr) {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+            };
+            auto issue = [&](auto ksc, auto ic, u32x4 (&f)[NRD]) {
+                constexpr int ks = decltype(ksc)::value, i = decltype(ic)::value;
+                if constexpr (i < 2) rd(f[i], ba[i] ^ (ks << 5));
+                else                 rd(f[i], aa[i - 2] ^ (ks << 5));
+            };
+            sfor<0, NRD>([&](auto ic) { issue(std::integral_constant<int, 0>{}, ic, fr[0]); });
+            sfor<0, 4>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
+                constexpr bool more = ks < 3;
+                u32x4 (&cur)[NRD] = fr[ks & 1];
+                u32x4 (&nxt)[NRD] = fr[(ks + 1) & 1];
+                sfor<0, NMF>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, m = j / 2, nt = j % 2;
+                    constexpr int issued = more ? (j < NRD ? j : NRD) : 0;
+                    if constexpr (nt == 0) {
+                        if constexpr (m == 0)
+                            asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]) : "n"(NRD - 3 + issued));
+                        else
+                            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[2 + m]) : "n"(NRD - (3 + m) + issued));
+                    }
+                    mma16(acc[m][nt], cur[2 + m], cur[nt], (const T*)nullptr);
+                    if constexpr (more && j < NRD) issue(std::integral_constant<int, ks + 1>{}, jc, nxt);
+                });
+            });
+        } else {
+            int abase[MT], aswz[MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const u32x4*>(ldsA + abase[m] + ((c ^ aswz[m]) << 4));
+            for (int m = 0; m < MT; ++m) {
+                const int row = a_row[m] + row_shift;
+                abase[m] = row * 128;
+                aswz[m] = swz(row);
+            }
+            const char* wb = ldsW + buf * W_BYTES;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const u32x4*>(wb + b_addr[nt] + ((c ^ b_swz[nt]) << 4));
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = 2 * ks + h;
+                u32x4 af[MT], bf[2];
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const u32x4*>(ldsA + abase[m] + ((c ^ aswz[m]) << 4));
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) mma16(acc[m][nt], af[m], bf[nt], (const T*)nullptr);
+                for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const u32x4*>(wb + b_addr[nt] + ((c ^ b_swz[nt]) << 4));
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) mma16(acc[m][nt], af[m], bf[nt], (const T*)nullptr);
+            }
         }
     };
 

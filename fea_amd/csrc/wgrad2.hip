@@ -77,12 +77,6 @@ __device__ __forceinline__ void wg2_issue(const Wgrad2Args& g, const __bf16* pg,
     }
 }
 
-// compile-time unrolled loop: f(std::integral_constant<int, I>) for I in [0, N)
-template <int I, int N, class F>
-__device__ __forceinline__ void sfor(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
-}
-
 // Transposing LDS read issued as inline asm: hipcc neither reorders it nor
 // waits for it -- the waits are the counted s_waitcnt of wg2_wait below.
 template <int OFF>
