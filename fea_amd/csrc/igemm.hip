@@ -34,6 +34,27 @@ struct IgemmArgs {
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
+// LDS read schedule of one tap of the bf16 path (see compute()): reads are issued
+// in a fixed order, the LDS returns them in order, so "read number i has
+// landed" == "at most issued - (i+1) reads outstanding".
+template <int MT16>
+struct TapSched {
+    static constexpr int S = 2 * MT16;
+    // k-step-1 B fragments read after slot i
+    static constexpr int nb(int i) { return MT16 == 8 ? ((i >= 2 && i <= 5) ? 1 : 0) : (i <= 1 ? 2 : 0); }
+    static constexpr int bfirst(int i) { int c = 0; for (int u = 0; u < i; ++u) c += nb(u); return c; }
+    static constexpr int na(int i) { return i + 3 < S ? 1 : 0; }
+    static constexpr int issued_before(int i) { int c = 7; for (int u = 0; u < i; ++u) c += nb(u) + na(u); return c; }
+    static constexpr int idxA(int s) { return s < 3 ? 4 + s : issued_before(s - 3) + nb(s - 3); }
+    static constexpr int idxBlast() {
+        int last = 0;
+        for (int i = 0; i < S; ++i) if (nb(i) > 0) last = issued_before(i) + nb(i) - 1;
+        return last;
+    }
+    static constexpr int need(int s) { int n = idxA(s); if (s == MT16 && idxBlast() > n) n = idxBlast(); return n; }
+    static constexpr int N(int s) { return issued_before(s) - (need(s) + 1); }
+};
+
 template <typename T, int MODE, int BN, int EPI>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     constexpr int CK = Elem<T>::CK, EPC = Elem<T>::EPC;
@@ -50,14 +71,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     constexpr int STAT_BYTES = WM * BN * 2 * 4;
     constexpr int MAIN_BYTES = A_BYTES + NWBUF * W_BYTES;
     constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES + STAT_BYTES ? MAIN_BYTES : EPI_BYTES + STAT_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    __shared__ __attribute__((aligned(128))) char smem[LDS_BYTES];
     char* const ldsA = smem;
     char* const ldsW = smem + A_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = BN == 128 ? (wave >> 1) : wave;
     const int wn = BN == 128 ? (wave & 1) : 0;
-    const int r = lane & 31, h = lane >> 5;
+    const int r = lane & 31, h = lane >> 5;          // fp32: 32x32x2 MFMA lane map
+    const int r16 = lane & 15, q16 = lane >> 4;      // bf16: 16x16x32 MFMA lane map
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int MT16 = MT * 2;                     // bf16: 16-row M tiles per wave (x 4 16-col N tiles)
 
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int ct = lid % g.nct;
@@ -108,28 +132,43 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     }
 
     // ---- per-lane fragment row descriptors ---------------------------------
-    int a_row[MT];                  // MODE 0: halo row of tap (0,0); else tile row
+    // fp32 (32x32x2): a_row[MT] / b rows of 32;  bf16 (16x16x32): a_row16[MT16] / 4 b rows of 16.
+    // A rows: MODE 0: halo row of tap (0,0); else tile row.
+    int a_row[MT], b_addr[2], b_swz[2];
+    int a_row16[MT16], b_row16[4];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int p = wm * (MT * 32) + m * 32 + r;
         a_row[m] = MODE == 0 ? (p >> tws) * (TW + 2) + (p & (TW - 1)) : p;
     }
-    int b_addr[2];                  // byte address of this lane's B row (chunk XOR folded in per k-step)
-    int b_swz[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int brow = wn * 64 + nt * 32 + r;
         b_addr[nt] = brow * 128;
         b_swz[nt] = swz(brow);
     }
+#pragma unroll
+    for (int m = 0; m < MT16; ++m) {
+        const int p = wm * (MT * 32) + m * 16 + r16;
+        a_row16[m] = MODE == 0 ? (p >> tws) * (TW + 2) + (p & (TW - 1)) : p;
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) b_row16[n] = wn * 64 + n * 16 + r16;
 
-    f32x16 acc[MT][2];
+    f32x16 acc[MT][2];              // fp32 path
+    f32x4 acc16[MT16][4];           // bf16 path
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT16; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc16[m][n][e] = 0.f;
 
     auto stage_A = [&](int chunk, int tap_off) {
         // global -> registers -> LDS in batches of 4 rows to bound live registers
@@ -177,43 +216,43 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     const uint32_t lds_a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ldsA;
     const uint32_t lds_w0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ldsW;
     auto compute = [&](int row_shift, int buf) {
-        if constexpr (sizeof(T) == 2) {
-            constexpr int NRD = MT + 2, NMF = 2 * MT;
-            uint32_t aa[MT], ba[2];
+        if constexpr (BF) {
+            // 16x16x32 MFMA.  A tap is S = 2*MT16 "slots" (k-step ks = s / MT16, M tile
+            // m = s % MT16), each 4 MFMAs sharing one A fragment.  A fragments run
+            // through a 4-deep ring read 3 slots ahead; the four B fragments of
+            // k-step 1 are read during k-step 0.  TapSched gives the counted waits.
+            typedef TapSched<MT16> TS;
+            constexpr int S = TS::S;
+            uint32_t aa[MT16], ba[4];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int row = a_row[m] + row_shift;
-                aa[m] = lds_a0 + row * 128 + ((h ^ swz(row)) << 4);
+            for (int m = 0; m < MT16; ++m) {
+                const int row = a_row16[m] + row_shift;
+                aa[m] = lds_a0 + row * 128 + ((q16 ^ swz(row)) << 4);
             }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) ba[nt] = lds_w0 + buf * W_BYTES + b_addr[nt] + ((h ^ b_swz[nt]) << 4);
-            u32x4 fr[2][NRD];                      // [0,1] = B, [2..] = A
+            for (int n = 0; n < 4; ++n) ba[n] = lds_w0 + buf * W_BYTES + b_row16[n] * 128 + ((q16 ^ swz(b_row16[n])) << 4);
+            u32x4 Ar[4], Br[2][4];
             auto rd = [&](u32x4& dst, uint32_t addr) {
                 asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
             };
-            auto issue = [&](auto ksc, auto ic, u32x4 (&f)[NRD]) {
-                constexpr int ks = decltype(ksc)::value, i = decltype(ic)::value;
-                if constexpr (i < 2) rd(f[i], ba[i] ^ (ks << 5));
-                else                 rd(f[i], aa[i - 2] ^ (ks << 5));
-            };
-            sfor<0, NRD>([&](auto ic) { issue(std::integral_constant<int, 0>{}, ic, fr[0]); });
-            sfor<0, 4>([&](auto ksc) {
-                constexpr int ks = decltype(ksc)::value;
-                constexpr bool more = ks < 3;
-                u32x4 (&cur)[NRD] = fr[ks & 1];
-                u32x4 (&nxt)[NRD] = fr[(ks + 1) & 1];
-                sfor<0, NMF>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value, m = j / 2, nt = j % 2;
-                    constexpr int issued = more ? (j < NRD ? j : NRD) : 0;
-                    if constexpr (nt == 0) {
-                        if constexpr (m == 0)
-                            asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]) : "n"(NRD - 3 + issued));
-                        else
-                            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[2 + m]) : "n"(NRD - (3 + m) + issued));
-                    }
-                    mma16(acc[m][nt], cur[2 + m], cur[nt], (const T*)nullptr);
-                    if constexpr (more && j < NRD) issue(std::integral_constant<int, ks + 1>{}, jc, nxt);
+            sfor<0, 4>([&](auto nc) { rd(Br[0][decltype(nc)::value], ba[decltype(nc)::value]); });
+            sfor<0, 3>([&](auto mc) { rd(Ar[decltype(mc)::value], aa[decltype(mc)::value]); });
+            sfor<0, S>([&](auto sc_) {
+                constexpr int s_ = decltype(sc_)::value, ks = s_ / MT16, m = s_ % MT16;
+                if constexpr (m == 0)
+                    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(Ar[s_ % 4]), "+v"(Br[ks][0]), "+v"(Br[ks][1]), "+v"(Br[ks][2]), "+v"(Br[ks][3])
+                                 : "n"(TS::N(s_)));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(Ar[s_ % 4]) : "n"(TS::N(s_)));
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc16[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Ar[s_ % 4]),
+                                                                          __builtin_bit_cast(bf16x8, Br[ks][n]), acc16[m][n], 0, 0, 0);
+                sfor<0, TS::nb(s_)>([&](auto jc) {
+                    constexpr int j = TS::bfirst(s_) + decltype(jc)::value;
+                    rd(Br[1][j], ba[j] ^ (1u << 6));
                 });
+                if constexpr (s_ + 3 < S) rd(Ar[(s_ + 3) % 4], aa[(s_ + 3) % MT16] ^ ((uint32_t)((s_ + 3) / MT16) << 6));
             });
         } else {
             int abase[MT], aswz[MT];
@@ -284,53 +323,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
 
     // ---- epilogue -----------------------------------------------------------
     const bool full = (y0 + TH <= H) && (x0 + TW <= W);
-    float bv[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = cout0 + wn * 64 + nt * 32 + r;
-        bv[nt] = g.bias ? g.bias[EPI == 1 ? col % g.Cup : col] : 0.f;
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][nt][e] += bv[nt];
-
-    if (EPI == 0 && g.stats) {
-        float* st = reinterpret_cast<float*>(smem + EPI_BYTES);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = acc[m][nt][e];
-                    if (!full) {
-                        const int p = wm * (MT * 32) + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        const bool ok = (y0 + (p >> tws) < H) && (x0 + (p & (TW - 1)) < W);
-                        v = ok ? v : 0.f;
-                    }
-                    s += v; q += v * v;
-                }
-            s += __shfl_xor(s, 32);
-            q += __shfl_xor(q, 32);
-            if (h == 0) {
-                st[(wm * BN + wn * 64 + nt * 32 + r) * 2 + 0] = s;
-                st[(wm * BN + wn * 64 + nt * 32 + r) * 2 + 1] = q;
-            }
-        }
-        __syncthreads();
-        if (tid < BN) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int w_ = 0; w_ < WM; ++w_) { s += st[(w_ * BN + tid) * 2]; q += st[(w_ * BN + tid) * 2 + 1]; }
-            float* dst = g.stats + ((long long)ptile * g.Cout + cout0 + tid) * 2;
-            dst[0] = s; dst[1] = q;
-        }
-    }
-
     // output addressing
     T* __restrict__ yg = (T*)g.y + (long long)n_img * g.y_img_stride;
     const int ab = EPI == 1 ? cout0 / g.Cup : 0;
@@ -340,19 +332,66 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
         ok = gy < H && gx < W;
         return EPI == 1 ? (2 * gy + (ab >> 1)) * (2 * W) + 2 * gx + (ab & 1) : gy * W + gx;
     };
+    float* st = reinterpret_cast<float*>(smem + EPI_BYTES);
 
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (BF) {
+        // 16x16 accumulator tiles: element j of acc16[m][n] is pixel
+        // wm*(MT*32) + m*16 + 4*q16 + j, column wn*64 + n*16 + r16.
+        float bv[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int col = cout0 + wn * 64 + n * 16 + r16;
+            bv[n] = g.bias ? g.bias[EPI == 1 ? col % g.Cup : col] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < MT16; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc16[m][n][j] += bv[n];
+
+        if (EPI == 0 && g.stats) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int m = 0; m < MT16; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc16[m][n][j];
+                        if (!full) {
+                            const int p = wm * (MT * 32) + m * 16 + 4 * q16 + j;
+                            const bool ok = (y0 + (p >> tws) < H) && (x0 + (p & (TW - 1)) < W);
+                            v = ok ? v : 0.f;
+                        }
+                        s += v; q += v * v;
+                    }
+                s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+                s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+                if (q16 == 0) {
+                    st[(wm * BN + wn * 64 + n * 16 + r16) * 2 + 0] = s;
+                    st[(wm * BN + wn * 64 + n * 16 + r16) * 2 + 1] = q;
+                }
+            }
+        }
         // stage the tile as [pixel][BN] bf16 in LDS, then store whole rows
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT16; ++m)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int n = 0; n < 4; ++n)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int p = wm * (MT * 32) + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    *reinterpret_cast<T*>(smem + p * EPI_STRIDE + (wn * 64 + nt * 32 + r) * 2) = from_f32<T>(acc[m][nt][e]);
+                for (int j = 0; j < 4; ++j) {
+                    const int p = wm * (MT * 32) + m * 16 + 4 * q16 + j;
+                    *reinterpret_cast<T*>(smem + p * EPI_STRIDE + (wn * 64 + n * 16 + r16) * 2) = from_f32<T>(acc16[m][n][j]);
                 }
         __syncthreads();
+        if (EPI == 0 && g.stats && tid < BN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w_ = 0; w_ < WM; ++w_) { s += st[(w_ * BN + tid) * 2]; q += st[(w_ * BN + tid) * 2 + 1]; }
+            float* dst = g.stats + ((long long)ptile * g.Cout + cout0 + tid) * 2;
+            dst[0] = s; dst[1] = q;
+        }
         constexpr int CPR = BN / 8;               // 16-byte chunks per row
 #pragma unroll
         for (int i = 0; i < CPR; ++i) {
@@ -365,6 +404,51 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
             }
         }
     } else {
+        float bv[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = cout0 + wn * 64 + nt * 32 + r;
+            bv[nt] = g.bias ? g.bias[EPI == 1 ? col % g.Cup : col] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][nt][e] += bv[nt];
+
+        if (EPI == 0 && g.stats) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = acc[m][nt][e];
+                        if (!full) {
+                            const int p = wm * (MT * 32) + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            const bool ok = (y0 + (p >> tws) < H) && (x0 + (p & (TW - 1)) < W);
+                            v = ok ? v : 0.f;
+                        }
+                        s += v; q += v * v;
+                    }
+                s += __shfl_xor(s, 32);
+                q += __shfl_xor(q, 32);
+                if (h == 0) {
+                    st[(wm * BN + wn * 64 + nt * 32 + r) * 2 + 0] = s;
+                    st[(wm * BN + wn * 64 + nt * 32 + r) * 2 + 1] = q;
+                }
+            }
+            __syncthreads();
+            if (tid < BN) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int w_ = 0; w_ < WM; ++w_) { s += st[(w_ * BN + tid) * 2]; q += st[(w_ * BN + tid) * 2 + 1]; }
+                float* dst = g.stats + ((long long)ptile * g.Cout + cout0 + tid) * 2;
+                dst[0] = s; dst[1] = q;
+            }
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
