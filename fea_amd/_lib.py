@@ -15,7 +15,7 @@ import torch
 
 F32, BF16 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfea_unet.so")
+LIB_PATH = os.environ.get("FEA_AMD_LIB") or os.path.join(_HERE, "libfea_unet.so")   # env override: A/B builds in scripts/
 
 P, I, L, F, Z = c_void_p, c_int, c_longlong, c_float, c_size_t
 

@@ -56,6 +56,11 @@ __device__ __forceinline__ void sfor(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
 }
 
+// bf16 conv3x3 with Cout (GEMM N) not a multiple of 128 runs the 64-column kernel, which
+// loads its weight fragments global -> VGPR and wants them packed in fragment order
+// (igemm.hip DB path, elementwise.hip pack_conv3x3_kernel).  One rule for both sides.
+__host__ __device__ inline bool fea_conv3x3_frag_pack(int gemm_n, int elem_bytes) { return elem_bytes == 2 && gemm_n % 128 != 0; }
+
 // host side -----------------------------------------------------------------
 void fea_set_error(const char* fmt, ...);
 #define FEA_CHECK(cond, code, ...) do { if (!(cond)) { fea_set_error(__VA_ARGS__); return (code); } } while (0)

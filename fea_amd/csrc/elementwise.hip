@@ -88,7 +88,12 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
     out[(((long long)n * H + yy) * W + xx) * ld + c] = from_f32<T>(x[(((long long)n * C + c) * H + yy) * W + xx]);
 }
 
-// packed conv3x3 weight: out[(chunk*9+tap)][row][j]
+// packed conv3x3 weight.  kc = chunk*9 + tap, row = GEMM N index, kk = channel inside the chunk.
+//   row-major:      out[kc][row][kk]                         (128-byte rows, staged through LDS)
+//   fragment order (bf16 and rows % 128 != 0, see fea_conv3x3_frag_pack):
+//         out[kc][row/16][kk/32][lane = ((kk/8)&3)*16 + row%16][kk%8]
+//         = the 16x16x32 MFMA B fragments in the order the conv kernel's waves load them
+//         (one contiguous KB per wave-instruction, global -> VGPR)
 template <typename T>
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int dgrad) {
     constexpr int CK = Elem<T>::CK;
@@ -97,14 +102,24 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
     const long long total = (long long)9 * rows * kch;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int j = (int)(i % CK);
-    const int row = (int)((i / CK) % rows);
-    const int kc = (int)(i / ((long long)CK * rows));
+    int row, kk, kc;
+    if (fea_conv3x3_frag_pack(rows, sizeof(T))) {
+        const int j = (int)(i & 7), ln = (int)((i >> 3) & 63), ks = (int)((i >> 9) & 1);
+        const long long blk = i >> 10;
+        const int nt16 = rows >> 4;
+        kc = (int)(blk / nt16);
+        row = (int)(blk % nt16) * 16 + (ln & 15);
+        kk = ks * 32 + (ln >> 4) * 8 + j;
+    } else {
+        kk = (int)(i % CK);
+        row = (int)((i / CK) % rows);
+        kc = (int)(i / ((long long)CK * rows));
+    }
     const int chunk = kc / 9, tap = kc - chunk * 9;
-    const int kk = chunk * CK + j;
+    const int kg = chunk * CK + kk;
     float v;
-    if (!dgrad) v = w[((long long)row * Ci + kk) * 9 + tap];
-    else        v = w[((long long)kk * Ci + row) * 9 + (8 - tap)];
+    if (!dgrad) v = w[((long long)row * Ci + kg) * 9 + tap];
+    else        v = w[((long long)kg * Ci + row) * 9 + (8 - tap)];
     out[i] = from_f32<T>(v);
 }
 template <typename T>

@@ -55,7 +55,7 @@ struct TapSched {
     static constexpr int N(int s) { return issued_before(s) - (need(s) + 1); }
 };
 
-template <typename T, int MODE, int BN, int EPI>
+template <typename T, int MODE, int BN, int EPI, int TWS>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     constexpr int CK = Elem<T>::CK, EPC = Elem<T>::EPC;
     constexpr int MT = BN == 128 ? 4 : 2;        // 32-row M tiles per wave
@@ -63,7 +63,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     constexpr int A_ROWS = MODE == 0 ? 352 : 256;
     constexpr int A_PASSES = A_ROWS / 32;        // 256 threads x 16 B = 32 rows per pass
     constexpr int A_BYTES = A_ROWS * 128;
-    constexpr int NWBUF = MODE == 0 ? 2 : 1;
+    // bf16 3x3: the weight (B) fragments go global -> VGPR directly, one tap ahead
+    // (fragment-ordered pack, 1 KB contiguous per wave-instruction): no weight tile
+    // in LDS and NO per-tap barrier; the A halo tile is the only LDS resident.
+    constexpr bool DB = MODE == 0 && sizeof(T) == 2 && BN == 64;   // (BN = 128: doubling the L2 weight traffic costs more than the barrier)
+    constexpr int NWBUF = DB ? 0 : (MODE == 0 ? 2 : 1);
     constexpr int W_BYTES = BN * 128;
     constexpr int W_PASSES = BN / 32;
     constexpr int EPI_STRIDE = BN * 2 + 16;      // bf16 staging row, padded
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     const int tile_y = pt % g.tiles_y;
     const int n_img = pt / g.tiles_y;
     const int cout0 = ct * BN;
-    const int tws = g.tw_shift, TW = 1 << tws, TH = 256 >> tws;
+    constexpr int tws = TWS, TW = 1 << tws, TH = 256 >> tws;
     const int y0 = tile_y * TH, x0 = tile_x * TW;
     const int H = g.H, W = g.W;
     const int nchunks = g.Cin / CK;
@@ -279,19 +283,115 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
         }
     };
 
-    if (MODE == 0) {
+    if constexpr (DB) {
+        const int HW2 = TW + 2;
+        constexpr int S = 2 * MT16;                 // slots per tap (multiple of 4: the A ring index carries across taps)
+        // B fragments: ring of three half-taps (one k-step of 32 = 4 fragments each),
+        // loaded two halves (= one tap) ahead of their use
+        u32x4 Ar[4], Hb[3][4];
+        auto rd = [&](u32x4& dst, uint32_t addr) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+        };
+        const int nhalf = nchunks * 18;
+        // packed weights: [kc][cout/16][ks][lane][8]
+        const int wn_u = __builtin_amdgcn_readfirstlane(wn);      // provably wave-uniform: scalar base + lane offset addressing
+        const T* wbase = wg + ((long long)((cout0 + wn_u * 64) >> 4) * 2) * 512;
+        const long long w_kc_stride = (long long)(g.Cout >> 4) * 2 * 512;
+        auto load_half = [&](int half, u32x4 (&b)[4]) {
+            half = half < nhalf ? half : nhalf - 1;           // past the end: a harmless re-load
+            const T* src = wbase + (half >> 1) * w_kc_stride + (half & 1) * 512;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const u32x4*>(src + n * 1024 + lane * 8);
+        };
+        // Halo row of M tile m (p = p0 + 16 m): TW = 32: row0 + (m>>1)*HW2 + (m&1)*16, and a
+        // step of 16 rows leaves the swizzle ((row>>1)&7) unchanged, so odd tiles are the
+        // even tile's address + 2048 (an immediate); TW = 16: row0 + m*HW2.
+        constexpr bool PAIR = TWS == 5;
+        constexpr int NAA = PAIR ? MT16 / 2 : MT16;
+        const int a_row0 = a_row16[0];
+        auto a_addr = [&](int i, int row_shift) -> uint32_t {       // i-th address register
+            const int row = a_row0 + row_shift + i * HW2;
+            return lds_a0 + row * 128 + ((q16 ^ swz(row)) << 4);
+        };
+        auto rd_a = [&](u32x4& dst, const uint32_t* ad, auto mc, uint32_t flip) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (PAIR) {
+                if constexpr (m & 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(dst) : "v"(ad[m >> 1] ^ flip) : "memory");
+                else                 asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(ad[m >> 1] ^ flip) : "memory");
+            } else {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(ad[m] ^ flip) : "memory");
+            }
+        };
+        // one tap: S slots of 4 MFMAs; A fragments through a 4-deep ring read 3 slots
+        // ahead, continuing into the next tap (after tap 8 the three look-ahead reads
+        // fetch tap 0 of the tile being replaced: never used, re-read after staging).
+        // half0 = index of this tap's first half-tap; its fragments are in Hb[BI], Hb[(BI+1)%3].
+        auto tap_mma = [&](int tap, int half0, auto bic) {
+            constexpr int BI = decltype(bic)::value;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int rs = dy * HW2 + dx;
+            const int tn = tap == 8 ? 0 : tap + 1, dyn = tn / 3, dxn = tn - dyn * 3;
+            const int rsn = dyn * HW2 + dxn;
+            uint32_t aa[NAA], aan[PAIR ? 2 : 3];
+#pragma unroll
+            for (int i = 0; i < NAA; ++i) aa[i] = a_addr(i, rs);
+#pragma unroll
+            for (int i = 0; i < (PAIR ? 2 : 3); ++i) aan[i] = a_addr(i, rsn);
+            sfor<0, S>([&](auto sc_) {
+                constexpr int s_ = decltype(sc_)::value, ks = s_ / MT16, m = s_ % MT16;
+                if constexpr (s_ == 0) load_half(half0 + 2, Hb[(BI + 2) % 3]);
+                if constexpr (s_ == MT16) load_half(half0 + 3, Hb[BI]);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(Ar[s_ % 4]));
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc16[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Ar[s_ % 4]),
+                                                                          __builtin_bit_cast(bf16x8, Hb[(BI + ks) % 3][n]), acc16[m][n], 0, 0, 0);
+                if constexpr (s_ + 3 < S)
+                    rd_a(Ar[(s_ + 3) % 4], aa, std::integral_constant<int, (s_ + 3) % MT16>{}, (uint32_t)((s_ + 3) / MT16) << 6);
+                else
+                    rd_a(Ar[(s_ + 3) % 4], aan, std::integral_constant<int, s_ + 3 - S>{}, 0u);
+            });
+        };
+        load_half(0, Hb[0]);
+        load_half(1, Hb[1]);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            __syncthreads();                       // previous chunk fully consumed
+            stage_A(ch, 0);
+            __syncthreads();
+            {
+                uint32_t a0[PAIR ? 2 : 3];
+#pragma unroll
+                for (int i = 0; i < (PAIR ? 2 : 3); ++i) a0[i] = a_addr(i, 0);
+                sfor<0, 3>([&](auto mc) { rd_a(Ar[decltype(mc)::value], a0, mc, 0u); });
+            }
+            const int h0 = ch * 18;
+#pragma unroll 1
+            for (int t3 = 0; t3 < 3; ++t3) {
+                tap_mma(3 * t3, h0 + 6 * t3, std::integral_constant<int, 0>{});
+                tap_mma(3 * t3 + 1, h0 + 6 * t3 + 2, std::integral_constant<int, 2>{});
+                tap_mma(3 * t3 + 2, h0 + 6 * t3 + 4, std::integral_constant<int, 1>{});
+            }
+        }
+    } else if (MODE == 0) {
         const int HW2 = TW + 2;
         for (int ch = 0; ch < nchunks; ++ch) {
             __syncthreads();                       // previous chunk fully consumed
             {
                 u32x4 wv[W_PASSES];
                 load_W(ch * 9, wv);
+#ifdef FEA_DBG_SKIP_A
+                if (ch == 0)
+#endif
                 stage_A(ch, 0);
                 write_W(0, wv);
             }
             __syncthreads();
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
+#ifdef FEA_DBG_SKIP_W
+                const int dy = tap / 3, dx = tap - dy * 3;
+                compute(dy * HW2 + dx, 0);
+#else
                 u32x4 wv[W_PASSES];
                 if (tap < 8) load_W(ch * 9 + tap + 1, wv);
                 const int dy = tap / 3, dx = tap - dy * 3;
@@ -300,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
                     write_W((tap + 1) & 1, wv);
                     __syncthreads();
                 }
+#endif
             }
         }
     } else {
@@ -480,14 +581,19 @@ static int launch_igemm(IgemmArgs& a, int N, hipStream_t s) {
     a.tw_shift = tws;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
-    const bool bn128 = (a.Cout % 128 == 0) && !(EPI == 1 && a.Cup % 128 != 0);
+    const bool bn128 = (a.Cout % 128 == 0) && !(EPI == 1 && a.Cup % 128 != 0);   // MODE 0: must agree with fea_conv3x3_frag_pack
     const int BN = bn128 ? 128 : 64;
     a.nct = a.Cout / BN;
     const long long nblk = (long long)N * a.tiles_x * a.tiles_y * a.nct;
     FEA_CHECK(nblk > 0 && nblk < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "igemm: grid of %lld blocks", nblk);
     dim3 grid((unsigned)nblk), block(256);
-    if (bn128) hipLaunchKernelGGL((igemm_kernel<T, MODE, 128, EPI>), grid, block, 0, s, a);
-    else       hipLaunchKernelGGL((igemm_kernel<T, MODE, 64, EPI>), grid, block, 0, s, a);
+    if (tws == 5) {
+        if (bn128) hipLaunchKernelGGL((igemm_kernel<T, MODE, 128, EPI, 5>), grid, block, 0, s, a);
+        else       hipLaunchKernelGGL((igemm_kernel<T, MODE, 64, EPI, 5>), grid, block, 0, s, a);
+    } else {
+        if (bn128) hipLaunchKernelGGL((igemm_kernel<T, MODE, 128, EPI, 4>), grid, block, 0, s, a);
+        else       hipLaunchKernelGGL((igemm_kernel<T, MODE, 64, EPI, 4>), grid, block, 0, s, a);
+    }
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }
