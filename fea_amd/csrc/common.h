@@ -43,6 +43,18 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
 
+// Sum of x over the four 16-lane rows of the wave (lanes l, l^16, l^32, l^48), in every
+// lane, on the VALU (gfx950 v_permlane16/32_swap; no LDS round trip).  Inline asm: the
+// builtins mis-handle identical operands in hipcc 7.2.  s_nop 1 = the two wait states
+// required between a VALU write of an operand and the swap.
+__device__ __forceinline__ float row_sum4(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a += b; b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 // XCD-aware bijective block remap (blocks b and b+8 share an XCD/L2): each XCD
 // gets a contiguous range of logical tile ids.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
 
     auto stage_A = [&](int chunk, int tap_off) {
         // global -> registers -> LDS in batches of 4 rows to bound live registers
-        constexpr int BATCH = 4;
+        constexpr int BATCH = BN == 64 ? 6 : 4;      // (the 64-column kernel has registers to spare: fewer round trips)
 #pragma unroll
         for (int b0 = 0; b0 < A_PASSES; b0 += BATCH) {
             u32x4 v[BATCH];
@@ -467,8 +467,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
                         }
                         s += v; q += v * v;
                     }
-                s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
-                s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+                s = row_sum4(s); q = row_sum4(q);
                 if (q16 == 0) {
                     st[(wm * BN + wn * 64 + n * 16 + r16) * 2 + 0] = s;
                     st[(wm * BN + wn * 64 + n * 16 + r16) * 2 + 1] = q;
