@@ -43,6 +43,9 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
 
+// 128 zero bytes: the source of LDS-DMA loads for out-of-image (zero padding) rows.
+static __device__ __attribute__((aligned(128))) const uint32_t fea_zero_line[32] = {0};
+
 // Sum of x over the four 16-lane rows of the wave (lanes l, l^16, l^32, l^48), in every
 // lane, on the VALU (gfx950 v_permlane16/32_swap; no LDS round trip).  Inline asm: the
 // builtins mis-handle identical operands in hipcc 7.2.  s_nop 1 = the two wait states

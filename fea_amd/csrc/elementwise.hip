@@ -293,57 +293,77 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int j = 0; j < V; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
 
-    for (long long it = it0 + slot; it < it1; it += slots) {
-        long long t = it;
-        const int xo = (int)(t % Wo); t /= Wo;
-        const int yo = (int)(t % Ho);
-        const int n = (int)(t / Ho);
-        constexpr int NP = POOL ? 4 : 1;
-        float yv[NP][V], g[NP][V];
-        long long pidx[NP];
+    // UN items per iteration: all loads of the batch are issued before the first use
+    // (memory-level parallelism; the loop is otherwise one dependent round trip per item)
+    constexpr int NP = POOL ? 4 : 1;
+    constexpr int UN = POOL ? 1 : (APPLY ? 2 : 4);
+    for (long long itb = it0 + slot; itb < it1; itb += (long long)slots * UN) {
+        u32x4 ry[UN][NP], rg[UN][NP], rp[UN];
+        long long pidx[UN][NP];
+        bool live[UN];
 #pragma unroll
-        for (int w4 = 0; w4 < NP; ++w4) {
-            pidx[w4] = POOL ? ((long long)n * H + 2 * yo + (w4 >> 1)) * W + 2 * xo + (w4 & 1)
-                            : ((long long)n * H + yo) * W + xo;
-            unpack<T>(*reinterpret_cast<const u32x4*>(y + pidx[w4] * C + grp * V), yv[w4]);
-            if (da_full) unpack<T>(*reinterpret_cast<const u32x4*>(da_full + pidx[w4] * ld_da + grp * V), g[w4]);
-            else {
+        for (int u = 0; u < UN; ++u) {
+            const long long it = itb + (long long)u * slots;
+            live[u] = it < it1;
+            long long t = live[u] ? it : itb;
+            const int xo = (int)(t % Wo); t /= Wo;
+            const int yo = (int)(t % Ho);
+            const int n = (int)(t / Ho);
 #pragma unroll
-                for (int j = 0; j < V; ++j) g[w4][j] = 0.f;
+            for (int w4 = 0; w4 < NP; ++w4) {
+                pidx[u][w4] = POOL ? ((long long)n * H + 2 * yo + (w4 >> 1)) * W + 2 * xo + (w4 & 1)
+                                   : ((long long)n * H + yo) * W + xo;
+                ry[u][w4] = *reinterpret_cast<const u32x4*>(y + pidx[u][w4] * C + grp * V);
+                if (da_full) rg[u][w4] = *reinterpret_cast<const u32x4*>(da_full + pidx[u][w4] * ld_da + grp * V);
             }
-        }
-        if (POOL && dpool) {
-            float dp[V];
-            unpack<T>(*reinterpret_cast<const u32x4*>(dpool + (((long long)n * Ho + yo) * Wo + xo) * C + grp * V), dp);
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                // first maximum in row-major window order (MaxPool2d backward, models.py:24)
-                float best = bn_act(yv[0][j], sc[j], sh[j]);
-                int bi = 0;
-#pragma unroll
-                for (int w4 = 1; w4 < NP; ++w4) {
-                    const float a = bn_act(yv[w4][j], sc[j], sh[j]);
-                    if (a > best) { best = a; bi = w4; }
-                }
-#pragma unroll
-                for (int w4 = 0; w4 < NP; ++w4) g[w4][j] += (bi == w4) ? dp[j] : 0.f;
-            }
+            if (POOL && dpool) rp[u] = *reinterpret_cast<const u32x4*>(dpool + (((long long)n * Ho + yo) * Wo + xo) * C + grp * V);
         }
 #pragma unroll
-        for (int w4 = 0; w4 < NP; ++w4) {
-            float o[V];
+        for (int u = 0; u < UN; ++u) {
+            if (!live[u]) continue;
+            float yv[NP][V], g[NP][V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const float act = bn_act(yv[w4][j], sc[j], sh[j]);
-                const float gg = act > 0.f ? g[w4][j] : 0.f;
-                const float xh = (yv[w4][j] - mu[j]) * is[j];
-                if (!APPLY) { a0[j] += gg; a1[j] += gg * xh; }
+            for (int w4 = 0; w4 < NP; ++w4) {
+                unpack<T>(ry[u][w4], yv[w4]);
+                if (da_full) unpack<T>(rg[u][w4], g[w4]);
                 else {
-                    const float d = sc[j] * (gg - c1[j] - xh * c2[j]);
-                    o[j] = d; a0[j] += d;
+#pragma unroll
+                    for (int j = 0; j < V; ++j) g[w4][j] = 0.f;
                 }
             }
-            if (APPLY) *reinterpret_cast<u32x4*>(dy + pidx[w4] * C + grp * V) = pack<T>(o);
+            if (POOL && dpool) {
+                float dp[V];
+                unpack<T>(rp[u], dp);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    // first maximum in row-major window order (MaxPool2d backward, models.py:24)
+                    float best = bn_act(yv[0][j], sc[j], sh[j]);
+                    int bi = 0;
+#pragma unroll
+                    for (int w4 = 1; w4 < NP; ++w4) {
+                        const float a = bn_act(yv[w4][j], sc[j], sh[j]);
+                        if (a > best) { best = a; bi = w4; }
+                    }
+#pragma unroll
+                    for (int w4 = 0; w4 < NP; ++w4) g[w4][j] += (bi == w4) ? dp[j] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int w4 = 0; w4 < NP; ++w4) {
+                float o[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float act = bn_act(yv[w4][j], sc[j], sh[j]);
+                    const float gg = act > 0.f ? g[w4][j] : 0.f;
+                    const float xh = (yv[w4][j] - mu[j]) * is[j];
+                    if (!APPLY) { a0[j] += gg; a1[j] += gg * xh; }
+                    else {
+                        const float d = sc[j] * (gg - c1[j] - xh * c2[j]);
+                        o[j] = d; a0[j] += d;
+                    }
+                }
+                if (APPLY) *reinterpret_cast<u32x4*>(dy + pidx[u][w4] * C + grp * V) = pack<T>(o);
+            }
         }
     }
     // reduce over the pixel slots of this block, fixed order

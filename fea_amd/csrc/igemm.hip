@@ -107,9 +107,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     // MODE 0 stages once per nine taps, so its offsets are recomputed at each
     // staging (saves 11 live registers); the gather modes stage every k-chunk
     // and keep theirs.
-    const int sc = tid & 7;         // 16-byte chunk of the 128-byte row this thread moves
+    // Staging is LDS-DMA (global_load_lds, 16 B per lane): wave-instruction j = 4 i + wave
+    // fills LDS rows 8j .. 8j+7 linearly, lane -> (row 8j + lane/8, 16-byte slot lane%8).
+    // The XOR swizzle is applied on the SOURCE: slot s of a row holds global chunk s ^ swz(row).
+    const int sc = tid & 7;         // LDS slot of the 128-byte row this lane fills
     auto a_desc = [&](int i, bool& ok) -> int {
         const int row = i * 32 + (tid >> 3);
+        const int sc = (tid & 7) ^ swz(row);      // source chunk
         int gy, gx;
         if (MODE == 0) {
             const int HW2 = TW + 2;
@@ -174,43 +178,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc16[m][n][e] = 0.f;
 
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef __attribute__((address_space(1))) const void gbl_void_t;
     auto stage_A = [&](int chunk, int tap_off) {
-        // global -> registers -> LDS in batches of 4 rows to bound live registers
-        constexpr int BATCH = BN == 64 ? 6 : 4;      // (the 64-column kernel has registers to spare: fewer round trips)
 #pragma unroll
-        for (int b0 = 0; b0 < A_PASSES; b0 += BATCH) {
-            u32x4 v[BATCH];
-            bool okv[BATCH];
-#pragma unroll
-            for (int i = 0; i < BATCH; ++i) {
-                if (b0 + i < A_PASSES) {
-                    int off;
-                    if constexpr (MODE == 0) off = a_desc(b0 + i, okv[i]);
-                    else { off = a_off[b0 + i]; okv[i] = (a_valid >> (b0 + i)) & 1; }
-                    const T* src = xg + off + (okv[i] ? tap_off : 0) + chunk * CK;
-                    v[i] = *reinterpret_cast<const u32x4*>(src);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < BATCH; ++i) {
-                if (b0 + i < A_PASSES) {
-                    const int row = (b0 + i) * 32 + (tid >> 3);
-                    u32x4 z = {0u, 0u, 0u, 0u};
-                    *reinterpret_cast<u32x4*>(ldsA + row * 128 + ((sc ^ swz(row)) << 4)) = okv[i] ? v[i] : z;
-                }
-            }
+        for (int i = 0; i < A_PASSES; ++i) {
+            int off; bool ok;
+            if constexpr (MODE == 0) off = a_desc(i, ok);
+            else { off = a_off[i]; ok = (a_valid >> i) & 1; }
+            const T* src = ok ? xg + off + tap_off + chunk * CK : reinterpret_cast<const T*>(fea_zero_line);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ldsA + (i * 4 + wave) * 1024), 16, 0, 0);
         }
     };
-    auto load_W = [&](int kc, u32x4 (&v)[W_PASSES]) {
-        const T* src = wg + ((long long)kc * g.Cout + cout0) * CK + tid * EPC;
-#pragma unroll
-        for (int j = 0; j < W_PASSES; ++j) v[j] = *reinterpret_cast<const u32x4*>(src + j * 256 * EPC);
-    };
-    auto write_W = [&](int buf, const u32x4 (&v)[W_PASSES]) {
+    auto stage_W = [&](int kc, int buf) {
 #pragma unroll
         for (int j = 0; j < W_PASSES; ++j) {
             const int row = j * 32 + (tid >> 3);
-            *reinterpret_cast<u32x4*>(ldsW + buf * W_BYTES + row * 128 + ((sc ^ swz(row)) << 4)) = v[j];
+            const T* src = wg + ((long long)kc * g.Cout + cout0 + row) * CK + ((sc ^ swz(row)) * EPC);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ldsW + buf * W_BYTES + (j * 4 + wave) * 1024), 16, 0, 0);
         }
     };
     // One tap (or one gathered k-chunk): 4 k-steps of 16.  bf16: the LDS reads
@@ -281,6 +266,56 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
                     for (int nt = 0; nt < 2; ++nt) mma16(acc[m][nt], af[m], bf[nt], (const T*)nullptr);
             }
         }
+    };
+
+    // MODE 0, bf16, weights through LDS (BN = 128): the taps of a chunk are chained.
+    // The A ring runs on into the next tap (its first three fragments are read during
+    // the last three slots), the next tap's weight tile is written to LDS in mid-tap
+    // (`mid`), so that after the per-tap barrier only the four B fragments of k-step 0
+    // are outstanding before the first MFMA.
+    u32x4 ArC[4];
+    auto a_addr16 = [&](int m, int row_shift) -> uint32_t {
+        const int row = a_row16[m] + row_shift;
+        return lds_a0 + row * 128 + ((q16 ^ swz(row)) << 4);
+    };
+    auto rd128 = [&](u32x4& dst, uint32_t addr) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+    };
+    auto compute_cont = [&](int row_shift, int next_shift, int buf, auto&& mid) {
+        typedef TapSched<MT16> TS;
+        constexpr int S = TS::S;
+        uint32_t aa[MT16], aan[3], ba[4];
+#pragma unroll
+        for (int m = 0; m < MT16; ++m) aa[m] = a_addr16(m, row_shift);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) aan[m] = a_addr16(m, next_shift);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) ba[n] = lds_w0 + buf * W_BYTES + b_row16[n] * 128 + ((q16 ^ swz(b_row16[n])) << 4);
+        u32x4 Br[2][4];
+        sfor<0, 4>([&](auto nc) { rd128(Br[0][decltype(nc)::value], ba[decltype(nc)::value]); });
+        sfor<0, S>([&](auto sc_) {
+            constexpr int s_ = decltype(sc_)::value, ks = s_ / MT16, m = s_ % MT16;
+            // reads issued after A(s): those of the two previous slots (slot 0: everything
+            // must have landed, the B fragments were issued last).  LDS writes of `mid`
+            // are not counted: the waits around it only get more conservative.
+            constexpr int N = s_ == 0 ? 0 : (s_ == 1 ? TS::nb(0) + 1 : (s_ == 2 ? TS::nb(0) + TS::nb(1) + 2 : TS::nb(s_ - 2) + TS::nb(s_ - 1) + 2));
+            if constexpr (s_ == MT16) mid();
+            if constexpr (m == 0)
+                asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ArC[s_ % 4]), "+v"(Br[ks][0]), "+v"(Br[ks][1]), "+v"(Br[ks][2]), "+v"(Br[ks][3])
+                             : "n"(N) : "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ArC[s_ % 4]) : "n"(N));
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc16[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ArC[s_ % 4]),
+                                                                      __builtin_bit_cast(bf16x8, Br[ks][n]), acc16[m][n], 0, 0, 0);
+            sfor<0, TS::nb(s_)>([&](auto jc) {
+                constexpr int j = TS::bfirst(s_) + decltype(jc)::value;
+                rd128(Br[1][j], ba[j] ^ (1u << 6));
+            });
+            if constexpr (s_ + 3 < S) rd128(ArC[(s_ + 3) % 4], aa[(s_ + 3) % MT16] ^ ((uint32_t)((s_ + 3) / MT16) << 6));
+            else rd128(ArC[(s_ + 3) % 4], aan[s_ + 3 - S]);
+        });
     };
 
     if constexpr (DB) {
@@ -372,35 +407,38 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
                 tap_mma(3 * t3 + 2, h0 + 6 * t3 + 4, std::integral_constant<int, 1>{});
             }
         }
+    } else if (MODE == 0 && BF) {
+        const int HW2 = TW + 2;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            __syncthreads();                       // previous chunk fully consumed
+            stage_W(ch * 9, 0);
+            stage_A(ch, 0);
+            __syncthreads();                       // (drains the LDS-DMA: vmcnt(0) before the barrier)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) rd128(ArC[m], a_addr16(m, 0));
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                // the buffer of tap+1 was last read in tap-1, which every wave has left
+                if (tap < 8) stage_W(ch * 9 + tap + 1, (tap + 1) & 1);
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const int tn = tap == 8 ? 0 : tap + 1, dyn = tn / 3, dxn = tn - dyn * 3;   // (after tap 8: a harmless look-ahead)
+                compute_cont(dy * HW2 + dx, dyn * HW2 + dxn, tap & 1, [&]() {});
+                if (tap < 8) __syncthreads();
+            }
+        }
     } else if (MODE == 0) {
         const int HW2 = TW + 2;
         for (int ch = 0; ch < nchunks; ++ch) {
             __syncthreads();                       // previous chunk fully consumed
-            {
-                u32x4 wv[W_PASSES];
-                load_W(ch * 9, wv);
-#ifdef FEA_DBG_SKIP_A
-                if (ch == 0)
-#endif
-                stage_A(ch, 0);
-                write_W(0, wv);
-            }
+            stage_W(ch * 9, 0);
+            stage_A(ch, 0);
             __syncthreads();
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
-#ifdef FEA_DBG_SKIP_W
-                const int dy = tap / 3, dx = tap - dy * 3;
-                compute(dy * HW2 + dx, 0);
-#else
-                u32x4 wv[W_PASSES];
-                if (tap < 8) load_W(ch * 9 + tap + 1, wv);
+                if (tap < 8) stage_W(ch * 9 + tap + 1, (tap + 1) & 1);
                 const int dy = tap / 3, dx = tap - dy * 3;
                 compute(dy * HW2 + dx, tap & 1);
-                if (tap < 8) {
-                    write_W((tap + 1) & 1, wv);
-                    __syncthreads();
-                }
-#endif
+                if (tap < 8) __syncthreads();
             }
         }
     } else {
@@ -411,11 +449,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
             const int tap = MODE == 2 ? kc / nchunks : 0;
             const int ch = kc - tap * nchunks;
             const int tap_off = MODE == 2 ? ((tap >> 1) * (2 * W) + (tap & 1)) * g.ldx : 0;
-            u32x4 wv[W_PASSES];
-            load_W(kc, wv);
             __syncthreads();                       // previous k-chunk consumed
+            stage_W(kc, 0);
             stage_A(ch, tap_off);
-            write_W(0, wv);
             __syncthreads();
             compute(0, 0);
         }

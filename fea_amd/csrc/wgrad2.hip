@@ -24,7 +24,6 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
-__device__ __attribute__((aligned(128))) const uint32_t fea_zero_line[32] = {0};
 
 struct Wgrad2Args {
     const __bf16* p; const __bf16* q; float* out;     // out: slab [split][M][Nn][9] (or dW itself when splits == 1)
