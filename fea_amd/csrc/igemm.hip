@@ -16,6 +16,10 @@
 //   EPI 0   y[pixel][cout0+col] (+bias, + BatchNorm partial sums)
 //   EPI 1   pixel-shuffle store of ConvTranspose2d forward: GEMM column
 //           n = ab*Cup + co goes to pixel (2i+a, 2j+b), channel co.
+//   EPI 2   EPI 0 + the first pass of the NEXT BatchNorm backward fused into the
+//           store loop: the tile just computed is an activation gradient da; with the
+//           layer's pre-BN output y, (sum g, sum g*xhat) per channel are written per
+//           pixel tile (g = da where relu(bn(y)) > 0), replacing fea_bn_relu_bwd_reduce.
 //
 // Reference layers served: nn.Conv2d(ci,co,3,padding=1) models.py:28,31 (fwd and
 // dgrad), nn.ConvTranspose2d(ci,co,2,stride=2) models.py:15-21 (fwd, bwd-data).
@@ -30,6 +34,11 @@ struct IgemmArgs {
     int Cup;           // EPI 1: channels per (a,b) quadrant
     int tw_shift, tiles_x, tiles_y;
     int nct;           // Cout / BN
+    // EPI 2: the output is the activation gradient da of a conv->BN->ReLU layer; reduce
+    // (sum g, sum g*xhat), g = da * (relu(bn(y)) > 0), per channel over the tile
+    const void* ybn; int ldybn;
+    const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
+    float* red_part;   // [pixel tile][Cout][2]
 };
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     constexpr int W_PASSES = BN / 32;
     constexpr int EPI_STRIDE = BN * 2 + 16;      // bf16 staging row, padded
     constexpr int EPI_BYTES = sizeof(T) == 2 ? 256 * EPI_STRIDE : 0;
-    constexpr int STAT_BYTES = WM * BN * 2 * 4;
+    constexpr int STAT_BYTES = 4 * BN * 2 * 4;     // per-wave partial sums [4][BN][2]
     constexpr int MAIN_BYTES = A_BYTES + NWBUF * W_BYTES;
     constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES + STAT_BYTES ? MAIN_BYTES : EPI_BYTES + STAT_BYTES;
     __shared__ __attribute__((aligned(128))) char smem[LDS_BYTES];
@@ -529,14 +538,78 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
             dst[0] = s; dst[1] = q;
         }
         constexpr int CPR = BN / 8;               // 16-byte chunks per row
+        if constexpr (EPI == 2) {
+            // thread -> fixed channel chunk c = tid % CPR, pixels tid / CPR + i * (256 / CPR)
+            const int c = tid % CPR;
+            float csc[8], csh[8], cmu[8], cis[8], a0[8], a1[8];
 #pragma unroll
-        for (int i = 0; i < CPR; ++i) {
-            const int q = i * 256 + tid;
-            const int p = q / CPR, c = q - p * CPR;
-            bool ok; const int pix = out_pix(p, ok);
-            if (ok) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + p * EPI_STRIDE + c * 16);
-                *reinterpret_cast<u32x4*>(yg + (long long)pix * g.ldy + c_off + c * 8) = v;
+            for (int j = 0; j < 8; ++j) {
+                const int ch = cout0 + c * 8 + j;
+                csc[j] = g.bn_scale[ch]; csh[j] = g.bn_shift[ch]; cmu[j] = g.bn_mean[ch]; cis[j] = g.bn_invstd[ch];
+                a0[j] = 0.f; a1[j] = 0.f;
+            }
+            const T* __restrict__ yb = (const T*)g.ybn + (long long)n_img * H * W * g.ldybn + cout0 + c * 8;
+            constexpr int GRP = 4;                    // y loads in flight per thread
+#pragma unroll
+            for (int i0 = 0; i0 < CPR; i0 += GRP) {
+                u32x4 yv[GRP]; int pixv[GRP]; bool okv[GRP];
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) {
+                    const int p = ((i0 + u) * 256 + tid) / CPR;
+                    pixv[u] = out_pix(p, okv[u]);
+                    yv[u] = *reinterpret_cast<const u32x4*>(yb + (long long)(okv[u] ? pixv[u] : 0) * g.ldybn);
+                }
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) {
+                    const int p = ((i0 + u) * 256 + tid) / CPR;
+                    if (okv[u]) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + p * EPI_STRIDE + c * 16);
+                        *reinterpret_cast<u32x4*>(yg + (long long)pixv[u] * g.ldy + c_off + c * 8) = v;
+                        const bf16x8 dv = __builtin_bit_cast(bf16x8, v), yy = __builtin_bit_cast(bf16x8, yv[u]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float yf = (float)yy[j];
+                            const float act = fmaxf(__builtin_fmaf(yf, csc[j], csh[j]), 0.f);   // == bn_act (elementwise.hip)
+                            const float gg = act > 0.f ? (float)dv[j] : 0.f;
+                            a0[j] += gg; a1[j] += gg * ((yf - cmu[j]) * cis[j]);
+                        }
+                    }
+                }
+            }
+            // lanes with equal lane % CPR hold the same channels: sum them on the VALU
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (CPR == 8) {
+                    a0[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0[j]), 0x128, 0xf, 0xf, false));
+                    a1[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a1[j]), 0x128, 0xf, 0xf, false));
+                }
+                a0[j] = row_sum4(a0[j]); a1[j] = row_sum4(a1[j]);
+            }
+            if (lane < CPR) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    st[((wave * BN) + lane * 8 + j) * 2 + 0] = a0[j];
+                    st[((wave * BN) + lane * 8 + j) * 2 + 1] = a1[j];
+                }
+            }
+            __syncthreads();
+            if (tid < BN) {
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int w_ = 0; w_ < 4; ++w_) { s0 += st[(w_ * BN + tid) * 2]; s1 += st[(w_ * BN + tid) * 2 + 1]; }
+                float* dst = g.red_part + ((long long)ptile * g.Cout + cout0 + tid) * 2;
+                dst[0] = s0; dst[1] = s1;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CPR; ++i) {
+                const int q = i * 256 + tid;
+                const int p = q / CPR, c = q - p * CPR;
+                bool ok; const int pix = out_pix(p, ok);
+                if (ok) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + p * EPI_STRIDE + c * 16);
+                    *reinterpret_cast<u32x4*>(yg + (long long)pix * g.ldy + c_off + c * 8) = v;
+                }
             }
         }
     } else {
@@ -668,6 +741,24 @@ extern "C" int fea_conv3x3(const void* x, int ldx, const void* w, const float* b
     a.ldx = ldx; a.ldy = ldy; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cup = Cout;
     a.x_img_stride = (long long)H * W * ldx; a.y_img_stride = (long long)H * W * ldy;
     return igemm_dispatch<0, 0>(a, N, dtype, stream);
+}
+
+extern "C" int fea_conv3x3_dgrad_bnred(const void* dy, int lddy, const void* w_packed, void* da, int ldda,
+                                       const void* y, int ldy_bn, const float* scale, const float* shift,
+                                       const float* save_mean, const float* save_invstd, float* part,
+                                       int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    int rc = check_common("fea_conv3x3_dgrad_bnred", dy, lddy, w_packed, da, ldda, N, H, W, Cin, Cout, dtype);
+    if (rc) return rc;
+    FEA_CHECK(dtype == FEA_BF16, FEA_E_UNSUPPORTED_SHAPE, "fea_conv3x3_dgrad_bnred: bf16 only (fp32: fea_conv3x3 + fea_bn_relu_bwd_reduce)");
+    FEA_CHECK(ldda >= Cout && y && scale && shift && save_mean && save_invstd && part, FEA_E_BADARG, "fea_conv3x3_dgrad_bnred: bad args");
+    FEA_CHECK(ldy_bn >= Cout && ldy_bn % 8 == 0 && ((uintptr_t)y % 16 == 0), FEA_E_BADARG, "fea_conv3x3_dgrad_bnred: y layout");
+    IgemmArgs a{};
+    a.x = dy; a.w = w_packed; a.bias = nullptr; a.y = da; a.stats = nullptr;
+    a.ldx = lddy; a.ldy = ldda; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cup = Cout;
+    a.x_img_stride = (long long)H * W * lddy; a.y_img_stride = (long long)H * W * ldda;
+    a.ybn = y; a.ldybn = ldy_bn; a.bn_scale = scale; a.bn_shift = shift; a.bn_mean = save_mean; a.bn_invstd = save_invstd;
+    a.red_part = part;
+    return launch_igemm<__bf16, 0, 2>(a, N, (hipStream_t)stream);
 }
 
 extern "C" int fea_conv1x1(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, float* stats,

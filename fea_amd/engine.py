@@ -127,7 +127,10 @@ class _Plan:
             ws = max(ws, lib.fea_wgrad_ws_bytes(2, N, h, w, 2 * c, c, code))
         self.ws_bytes = int(ws)
         self.ws = es(self.ws_bytes // 4, dtype=torch.float32, device=dev)
-        nb = max(L.call("fea_bn_bwd_blocks", N, *self.dims[LEVEL[b]], CH[b]) * CH[b] * 2 for b in BLOCKS)
+        # rows of `part`: the BN-backward kernels use fea_bn_bwd_blocks() rows, the fused
+        # dgrad epilogue (fea_conv3x3_dgrad_bnred) one row per conv pixel tile
+        nb = max(max(L.call("fea_bn_bwd_blocks", N, *self.dims[LEVEL[b]], CH[b]),
+                     L.call("fea_conv_num_tiles", N, *self.dims[LEVEL[b]])) * CH[b] * 2 for b in BLOCKS)
         nb = max(nb, 2048 * 1024 * 2)
         self.part = es(nb, dtype=torch.float32, device=dev)
         self.bncoef = es(1024 * 2, dtype=torch.float32, device=dev)
@@ -359,15 +362,23 @@ class UNetEngine:
                 for n in names:
                     self.grad_ready(n)
 
-        def bn_bwd(name, da_full, ld_da, dpool, h, w, c):
+        fuse = self.dtype == torch.bfloat16     # dgrad kernels also produce the next BN-backward's partial sums
+
+        def bn_bwd(name, da_full, ld_da, dpool, h, w, c, reduced_tiles=0):
+            """reduced_tiles > 0: pl.part already holds that many per-tile partial sums
+            (written by the kernel that produced da_full)."""
             blk, idx = name.rsplit(".", 1)
             bn = f"{blk}.{int(idx) + 1}"
             cf = pl.coef[name]
             y = pl.y[name]
             nblk = L.call("fea_bn_bwd_blocks", N, h, w, c)
-            L.call("fea_bn_relu_bwd_reduce", da_full, ld_da, dpool, y, cf["scale"], cf["shift"], cf["mean"], cf["invstd"],
-                   pl.part, N, h, w, c, code, S)
-            L.call("fea_bn_bwd_finalize", pl.part, nblk, N * h * w, P[bn + ".weight"], cf["invstd"],
+            if reduced_tiles:
+                nfin = reduced_tiles
+            else:
+                nfin = nblk
+                L.call("fea_bn_relu_bwd_reduce", da_full, ld_da, dpool, y, cf["scale"], cf["shift"], cf["mean"], cf["invstd"],
+                       pl.part, N, h, w, c, code, S)
+            L.call("fea_bn_bwd_finalize", pl.part, nfin, N * h * w, P[bn + ".weight"], cf["invstd"],
                    g[bn + ".weight"], g[bn + ".bias"], pl.bncoef, c, S)
             L.call("fea_bn_relu_bwd_apply", da_full, ld_da, dpool, y, cf["scale"], cf["shift"], cf["mean"], cf["invstd"],
                    pl.bncoef, pl.dY, pl.part, N, h, w, c, code, S)
@@ -380,8 +391,14 @@ class UNetEngine:
             bn_bwd(n3, da_full, ld_da, dpool, h, w, c)
             L.call("fea_conv3x3_wgrad", pl.dY, c, pl.a0[blk], c, g[n3 + ".weight"], pl.ws, pl.ws_bytes, N, h, w, c, c, code, S)
             done(n3 + ".weight", n3 + ".bias", f"{blk}.4.weight", f"{blk}.4.bias")
-            L.call("fea_conv3x3", pl.dY, c, self._w_dgrad(n3), None, pl.gmid, c, None, N, h, w, c, c, code, S)
-            bn_bwd(n0, pl.gmid, c, None, h, w, c)
+            if fuse:
+                cf0 = pl.coef[n0]
+                L.call("fea_conv3x3_dgrad_bnred", pl.dY, c, self._w_dgrad(n3), pl.gmid, c, pl.y[n0], c,
+                       cf0["scale"], cf0["shift"], cf0["mean"], cf0["invstd"], pl.part, N, h, w, c, c, code, S)
+                bn_bwd(n0, pl.gmid, c, None, h, w, c, reduced_tiles=L.call("fea_conv_num_tiles", N, h, w))
+            else:
+                L.call("fea_conv3x3", pl.dY, c, self._w_dgrad(n3), None, pl.gmid, c, None, N, h, w, c, c, code, S)
+                bn_bwd(n0, pl.gmid, c, None, h, w, c)
             if blk == "enc1":
                 L.call("fea_conv1x1_im2col_wgrad", pl.dY, c, pl.xcol, self.kpad, g[n0 + ".weight"], pl.ws, pl.ws_bytes,
                        N, h, w, self.kpad, self.in_channels, c, code, S)

@@ -83,6 +83,16 @@ int fea_pack_upconv2x2(const float* w, void* out, int Ci, int Co, int bwd, int d
  * valid pixels, taken from the fp32 accumulators (models.py:29,32 train mode). */
 int fea_conv3x3(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                 float* stats, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* Data gradient of conv3x3 (w_packed = dgrad pack, GEMM K = Cin = channels of dy, GEMM N =
+ * Cout = channels of da) whose output da is the activation gradient of a conv->BN->ReLU
+ * layer with pre-BN output y (models.py:28-33 backward).  The first pass of that layer's
+ * BatchNorm backward is fused into the store loop: part[fea_conv_num_tiles()][Cout][2] =
+ * per-tile (sum g, sum g*xhat), g = da where relu(y*scale+shift) > 0, xhat = (y-mean)*invstd;
+ * feed it to fea_bn_bwd_finalize with nblk = fea_conv_num_tiles().  bf16 only. */
+int fea_conv3x3_dgrad_bnred(const void* dy, int lddy, const void* w_packed, void* da, int ldda,
+                            const void* y, int ldy_bn, const float* scale, const float* shift,
+                            const float* save_mean, const float* save_invstd, float* part,
+                            int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
 /* 1x1 GEMM over pixel rows (enc1.0 on im2col rows); same epilogue as above. */
 int fea_conv1x1(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                 float* stats, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);

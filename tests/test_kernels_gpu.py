@@ -104,6 +104,38 @@ def test_conv3x3_fwd_stats_and_dgrad(dt, shape):
     check(from_nhwc(dx, ci), ref_dx, dt, "conv3x3 dgrad")
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64), (1, 24, 40, 128, 128), (1, 16, 16, 128, 256), (2, 64, 64, 128, 64)])
+def test_conv3x3_dgrad_with_fused_bn_backward_reduction(shape):
+    """fea_conv3x3_dgrad_bnred == fea_conv3x3 (dgrad pack) followed by fea_bn_relu_bwd_reduce:
+    identical da (bit for bit) and the same per-channel sums."""
+    n, h, w, ck, cn = shape                      # ck = channels of dy (GEMM K), cn = channels of da / y
+    dt = torch.bfloat16
+    code = L.dt_code(dt)
+    g = torch.Generator().manual_seed(11)
+    dy = rnd(dt, n, ck, h, w, gen=g)
+    wt = (rnd(dt, ck, cn, 3, 3, gen=g) / (3 * ck ** 0.5)).to(dt).float()      # Conv2d(cn -> ck).weight
+    y = rnd(dt, n, cn, h, w, gen=g)
+    scale, shift = torch.randn(cn, generator=g), torch.randn(cn, generator=g)
+    mean, invstd = torch.randn(cn, generator=g), torch.rand(cn, generator=g) + 0.5
+    dyd, yd = to_nhwc(dy, dt), to_nhwc(y, dt)
+    wpd = torch.empty(9 * ck * cn, dtype=dt, device=DEV)
+    L.call("fea_pack_conv3x3", wt.to(DEV), wpd, ck, cn, 1, code, S())
+    coef = [t.to(DEV) for t in (scale, shift, mean, invstd)]
+    da_ref = torch.full((n, h, w, cn), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_conv3x3", dyd, ck, wpd, None, da_ref, cn, None, n, h, w, ck, cn, code, S())
+    nblk = L.call("fea_bn_bwd_blocks", n, h, w, cn)
+    part_ref = torch.zeros(nblk, cn, 2, device=DEV)
+    L.call("fea_bn_relu_bwd_reduce", da_ref, cn, None, yd, *coef, part_ref, n, h, w, cn, code, S())
+    ntiles = L.call("fea_conv_num_tiles", n, h, w)
+    da = torch.full((n, h, w, cn), float("nan"), dtype=dt, device=DEV)
+    part = torch.full((ntiles, cn, 2), float("nan"), device=DEV)
+    L.call("fea_conv3x3_dgrad_bnred", dyd, ck, wpd, da, cn, yd, cn, *coef, part, n, h, w, ck, cn, code, S())
+    torch.cuda.synchronize()
+    assert torch.equal(da.view(torch.int16), da_ref.view(torch.int16)), "fused kernel changed the data gradient"
+    got, ref = part.double().sum(0).cpu(), part_ref.double().sum(0).cpu()
+    assert rel_l2(got, ref) < 1e-5, f"fused BN-backward sums: {rel_l2(got, ref):.3e}"
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64), (1, 16, 16, 128, 64), (1, 24, 40, 64, 128), (1, 8, 8, 64, 192)])
 def test_conv3x3_wgrad(dt, shape):
