@@ -47,6 +47,7 @@ SIGNATURES = {
     "fea_bn_bwd_finalize": (I, [P, I, L, P, P, P, P, P, I, P]),
     "fea_bn_relu_bwd_apply": (I, [P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "fea_reduce_partials": (I, [P, I, I, I, P, P]),
+    "fea_reduce_partials_n": (I, [P, I, I, I, I, P, P]),
     "fea_channel_sum": (I, [P, I, L, I, P, P, I, P]),
     "fea_head_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "fea_head_bwd_blocks": (I, [I, I, I]),

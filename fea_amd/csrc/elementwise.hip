@@ -640,6 +640,14 @@ extern "C" int fea_reduce_partials(const float* part, int nblk, int C, int slot,
     return FEA_OK;
 }
 
+extern "C" int fea_reduce_partials_n(const float* part, int nblk, int ld, int n, int slot, float* out, void* stream) {
+    FEA_CHECK(part && out && nblk > 0 && ld > 0 && n > 0 && n <= ld && (slot == 0 || slot == 1), FEA_E_BADARG,
+              "fea_reduce_partials_n: bad args");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, part, nblk, ld, slot, out);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
 extern "C" int fea_channel_sum(const void* x, int ld, long long npix, int C, float* part, int* nblk_out, int dtype, void* stream) {
     const int V = velems(dtype);
     FEA_CHECK(x && part && nblk_out && npix > 0 && C > 0, FEA_E_BADARG, "fea_channel_sum: bad args");

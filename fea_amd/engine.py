@@ -79,7 +79,8 @@ class _Plan:
             self.a0[blk] = es((N, h, w, c), dtype=dt, device=dev)
             if blk not in ENC:
                 self.a3[blk] = es((N, h, w, c), dtype=dt, device=dev)
-            max_stats = max(max_stats, L.call("fea_conv_num_tiles", N, h, w) * c * 2)
+            # forward: Cout columns; decoder dgrad of X.0 also takes sums of its 2*Cout-wide output
+            max_stats = max(max_stats, L.call("fea_conv_num_tiles", N, h, w) * (c if blk in ENC or blk == "bottleneck" else 2 * c) * 2)
         for k, blk in enumerate(ENC, start=1):
             h, w = self.dims[k - 1]
             c = CH[blk]
@@ -384,7 +385,7 @@ class UNetEngine:
                    pl.bncoef, pl.dY, pl.part, N, h, w, c, code, S)
             L.call("fea_reduce_partials", pl.part, nblk, c, 0, g[name + ".bias"], S)
 
-        def block_bwd(blk, da_full, ld_da, dpool, inp, ld_in, cin, d_in, ld_din):
+        def block_bwd(blk, da_full, ld_da, dpool, inp, ld_in, cin, d_in, ld_din, din_stats=None):
             h, w = pl.dims[LEVEL[blk]]
             c = CH[blk]
             n3, n0 = f"{blk}.3", f"{blk}.0"
@@ -406,7 +407,7 @@ class UNetEngine:
                 L.call("fea_conv3x3_wgrad", pl.dY, c, inp, ld_in, g[n0 + ".weight"], pl.ws, pl.ws_bytes, N, h, w, cin, c, code, S)
             done(n0 + ".weight", n0 + ".bias", f"{blk}.1.weight", f"{blk}.1.bias")
             if d_in is not None:
-                L.call("fea_conv3x3", pl.dY, c, self._w_dgrad(n0), None, d_in, ld_din, None, N, h, w, c, cin, code, S)
+                L.call("fea_conv3x3", pl.dY, c, self._w_dgrad(n0), None, d_in, ld_din, din_stats, N, h, w, c, cin, code, S)
 
         # head
         nblk = L.call("fea_head_bwd_blocks", N, H, W)
@@ -417,12 +418,13 @@ class UNetEngine:
         for k in (1, 2, 3, 4):
             blk = f"dec{k}"
             c = CH[blk]
-            block_bwd(blk, pl.G[0], c, None, pl.cat[k], 2 * c, 2 * c, pl.dcat[k], 2 * c)
+            # the dgrad that writes dcat[k] also emits per-tile channel sums of it: channels
+            # [0,c) summed over pixels = the transposed conv's bias gradient
+            block_bwd(blk, pl.G[0], c, None, pl.cat[k], 2 * c, 2 * c, pl.dcat[k], 2 * c, din_stats=pl.stats)
             hl, wl = pl.dims[k]
             src = pl.a3[f"dec{k + 1}"] if k < 4 else pl.a3["bottleneck"]
-            nb = ctypes.c_int(0)
-            L.call("fea_channel_sum", pl.dcat[k], 2 * c, N * 4 * hl * wl, c, pl.part, ctypes.byref(nb), code, S)
-            L.call("fea_reduce_partials", pl.part, nb.value, c, 0, g[f"upconv{k}.bias"], S)
+            L.call("fea_reduce_partials_n", pl.stats, L.call("fea_conv_num_tiles", N, 2 * hl, 2 * wl), 2 * c, c, 0,
+                   g[f"upconv{k}.bias"], S)
             L.call("fea_upconv2x2_wgrad", src, 2 * c, pl.dcat[k], 2 * c, g[f"upconv{k}.weight"], pl.ws, pl.ws_bytes,
                    N, hl, wl, 2 * c, c, code, S)
             done(f"upconv{k}.weight", f"upconv{k}.bias")

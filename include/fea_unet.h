@@ -158,6 +158,10 @@ int fea_bn_relu_bwd_apply(const void* da_full, int ld_da, const void* dpool, con
                           const float* coef, void* dy, float* part, int N, int H, int W, int C, int dtype, void* stream);
 /* sum over blocks of slot `slot` of part[nblk][C][2] -> out[C] (conv/upconv bias gradients). */
 int fea_reduce_partials(const float* part, int nblk, int C, int slot, float* out, void* stream);
+/* the same for the first n channels of rows that are ld channels wide.  With the `stats` of a
+ * dgrad fea_conv3x3 call that writes the concat-buffer gradient, slot 0 of channels [0,C) is the
+ * ConvTranspose2d bias gradient (models.py:15-21,42-45 backward). */
+int fea_reduce_partials_n(const float* part, int nblk, int ld, int n, int slot, float* out, void* stream);
 /* per-channel sum over all pixels of a [npix, C] (ld) tensor -> part[nblk][C][2] slot 0
  * (ConvTranspose2d bias gradient). */
 int fea_channel_sum(const void* x, int ld, long long npix, int C, float* part, int* nblk_out, int dtype, void* stream);
