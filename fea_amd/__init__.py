@@ -4,5 +4,6 @@
 """
 from .models import FloorPlanSegmentationModel  # noqa: F401
 from . import functional  # noqa: F401
+from .inference import Inference, TiledSegmenter  # noqa: F401
 
-__all__ = ["FloorPlanSegmentationModel", "functional"]
+__all__ = ["FloorPlanSegmentationModel", "functional", "Inference", "TiledSegmenter"]

@@ -62,3 +62,34 @@ def test_bucketed_allreduce_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+def _iou_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fea_amd.inference import reduce_counts
+        inter = torch.tensor([1, 20, 300, 0, 5, 6], dtype=torch.int64) * (rank + 1)
+        union = torch.tensor([2, 40, 600, 0, 7, 9], dtype=torch.int64) * (rank + 1) + (1 << 40)   # beyond fp32/fp64-exact float sums
+        i2, u2 = reduce_counts(inter, union)
+        q.put((rank, i2.tolist(), u2.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_iou_count_allreduce_world2_is_exact_int64():
+    """Inference shards images over ranks; the only exchange is the int64 (I, U) sum."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_iou_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_i = [3, 60, 900, 0, 15, 18]
+    want_u = [6 + (1 << 41), 120 + (1 << 41), 1800 + (1 << 41), (1 << 41), 21 + (1 << 41), 27 + (1 << 41)]
+    for _, i2, u2 in res:
+        assert i2 == want_i and u2 == want_u

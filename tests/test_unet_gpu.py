@@ -204,3 +204,39 @@ def test_loss_autograd_and_iou():
     (2 * loss).backward()
     assert rel_l2(xd.grad.cpu(), 2 * xr.grad) < 1e-4
     assert torch.equal(Fn.binarise_mask(torch.arange(256, dtype=torch.uint8).cuda()).cpu(), O.binarise_mask(torch.arange(256, dtype=torch.uint8)))
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_tiled_inference_equals_whole_image(dt):
+    """BASELINE configs[4] in miniature: windows of 64 + 2*96 px over a 384x384 image must
+    reproduce the whole-image eval logits (receptive-field radius 92 < halo 96), and the
+    thresholded masks / IoU counts must be identical."""
+    from fea_amd.inference import TiledSegmenter
+    from fea_amd import functional as Fn
+    torch.manual_seed(5)
+    m = fea_amd.FloorPlanSegmentationModel(compute_dtype=dt).to("cuda")
+    # non-trivial running statistics (eval mode uses them)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.uniform_(-0.2, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+    m.eval()
+    x, tgt = O.synthetic_batch(2, 384, 384, seed=9)
+    x = (x + 0.05 * torch.randn(x.shape, generator=torch.Generator().manual_seed(1))).to("cuda")
+    tgt = tgt.to("cuda")
+    with torch.no_grad():
+        whole = m(x)
+    seg = TiledSegmenter(m, core=64, window_batch=5)
+    tiled = seg.logits(x)
+    # identical arithmetic per output pixel -> agreement to rounding of the accumulation order
+    tol = 1e-5 if dt == "fp32" else 2e-2
+    assert rel_l2(tiled, whole) < tol, rel_l2(tiled, whole)
+    mask_t, it, ut = seg.segment(x, tgt)
+    mask_w, iw, uw = Fn.mask_iou_counts(whole, tgt)
+    if dt == "fp32":
+        flips = (mask_t != mask_w)
+        assert int(flips.sum()) <= int(((whole.abs() < 1e-4)).sum()), "mask differs away from logit ~ 0"
+    # IoU counts are exact for the logits they are computed from
+    _, ref_i, ref_u = O.mask_iou_counts(tiled.cpu(), tgt.cpu())
+    assert torch.equal(it.cpu(), ref_i) and torch.equal(ut.cpu(), ref_u)
