@@ -137,6 +137,21 @@ __global__ void pack_conv3x3_im2col_kernel(const float* __restrict__ w, T* __res
     if (k < 9 * C) { const int tap = k / C, c = k - tap * C; v = w[((long long)co * C + c) * 9 + tap]; }
     out[i] = from_f32<T>(v);
 }
+// first layer (fea_conv3x3_first): out[ks][co/16][lane = q*16 + co%16][j], k = ks*32 + q*8 + j = tap*C + c
+__global__ void pack_conv3x3_first_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Co, int C, int KS) {
+    const long long total = (long long)KS * Co * 32;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i & 7), ln = (int)((i >> 3) & 63);
+    const long long blk = i >> 9;
+    const int nt16 = Co >> 4;
+    const int ks = (int)(blk / nt16), co = (int)(blk % nt16) * 16 + (ln & 15);
+    const int k = ks * 32 + (ln >> 4) * 8 + j;
+    float v = 0.f;
+    if (k < 9 * C) { const int tap = k / C, c = k - tap * C; v = w[((long long)co * C + c) * 9 + tap]; }
+    out[i] = (__bf16)v;
+}
+
 template <typename T>
 __global__ void pack_upconv_kernel(const float* __restrict__ w, T* __restrict__ out, int Ci, int Co, int bwd) {
     constexpr int CK = Elem<T>::CK;
@@ -506,6 +521,15 @@ extern "C" int fea_pack_conv3x3_im2col(const float* w, void* out, int Co, int C,
     const long long total = (long long)Co * Kpad;
     DT_SWITCH(dtype, "fea_pack_conv3x3_im2col",
               hipLaunchKernelGGL((pack_conv3x3_im2col_kernel<T>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, w, (T*)out, Co, C, Kpad));
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_pack_conv3x3_first(const float* w, void* out, int Co, int C, int dtype, void* stream) {
+    FEA_CHECK(w && out && Co > 0 && Co % 16 == 0 && C > 0 && 9 * C <= 64 && dtype == FEA_BF16, FEA_E_BADARG, "fea_pack_conv3x3_first: bad args");
+    const int KS = (9 * C + 31) / 32;
+    const long long total = (long long)KS * Co * 32;
+    hipLaunchKernelGGL(pack_conv3x3_first_kernel, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)out, Co, C, KS);
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }

@@ -1,0 +1,220 @@
+// Weight gradient of the FIRST layer, enc1[0] = Conv2d(in_channels, 64, 3, padding=1)
+// (models.py:10,28), bf16 path:
+//
+//   dW[co][c][tap] = sum_p dy[p][co] * x[p + tap][c]       dy: NHWC bf16, x: fp32 NCHW
+//
+// GEMM view: M = co (64 per workgroup), N = 9*C (<= 64, index n = tap*C + c), reduction
+// over pixels.  HBM-bound on reading dy once (the input has 3 channels): the kernel only
+// has to keep enough bytes in flight.  One 256-thread workgroup walks a range of
+// 8 x 32-pixel tiles; each tile's dy rows and the fp32 halo of x are brought in by
+// LDS-DMA into a two-stage ring (loads of tile t+1 in flight while tile t is multiplied).
+// Each of the four waves takes two of the tile's eight 32-pixel rows (= MFMA k-steps,
+// v_mfma_f32_16x16x32_bf16): A (dy, k = pixel) comes from the transposing LDS read, B
+// is gathered from the fp32 halo and rounded to bf16 exactly as the forward kernel
+// (igemm.hip MODE 3) does.  The four waves are summed through LDS; workgroups write
+// fp32 slabs that a second kernel adds in a fixed order (deterministic).
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+struct FirstWgradArgs {
+    const __bf16* dy; const float* x; float* slab;
+    int lddy, C, H, W, Cout;
+    int tiles_x, tiles_y, ntiles, tiles_per_split;
+};
+
+constexpr int FW_HALO = 10 * 34;                 // floats per channel
+constexpr int FW_DY_BYTES = 256 * 128;
+constexpr int FW_X_BYTES = 10 * 1024;            // >= 7 * 340 * 4
+constexpr int FW_STAGE = FW_DY_BYTES + FW_X_BYTES;
+
+// 32-byte unit swizzle of the dy rows: rows read together by one ds_read_b64_tr_b16
+// half-wave ({x..x+3} and {x+8..x+11}, same 32-byte channel block) land in distinct banks
+__device__ __forceinline__ int fw_swz(int x) { return ((x >> 1) & 1) | (((x >> 3) & 1) << 1); }
+
+__device__ __forceinline__ void fw_issue(const FirstWgradArgs& g, int m0, int wave, int lane, int tile, char* sb,
+                                         const int (&xdesc)[10], int nxi) {
+    int tt = tile;
+    const int tile_x = tt % g.tiles_x; tt /= g.tiles_x;
+    const int tile_y = tt % g.tiles_y;
+    const int n_img = tt / g.tiles_y;
+    const int y0 = tile_y * 8, x0 = tile_x * 32;
+    const int H = g.H, W = g.W;
+    const __bf16* dimg = g.dy + (long long)n_img * H * W * g.lddy + m0;
+    const float* ximg = g.x + (long long)n_img * g.C * H * W;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = (it * 4 + wave) * 8 + (lane >> 3);
+        const int ty = row >> 5, tx = row & 31;
+        const int gy = y0 + ty, gx = x0 + tx;
+        const int chunk = (lane & 7) ^ (fw_swz(tx) << 1);
+        const __bf16* src = (gy < H && gx < W) ? dimg + (long long)(gy * W + gx) * g.lddy + chunk * 8
+                                               : reinterpret_cast<const __bf16*>(fea_zero_line);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sb + (it * 4 + wave) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+        if (it * 4 + wave < nxi) {                       // wave-uniform
+            const int d = xdesc[it];                      // c | hy << 8 | hx << 16 | invalid << 24
+            const int c = d & 0xff, gy = y0 + ((d >> 8) & 0xff) - 1, gx = x0 + ((d >> 16) & 0xff) - 1;
+            const bool ok = !(d >> 24) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float* src = ok ? ximg + ((long long)c * H + gy) * W + gx : reinterpret_cast<const float*>(fea_zero_line);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sb + FW_DY_BYTES + (it * 4 + wave) * 256), 4, 0, 0);
+        }
+    }
+}
+
+// Multiply the tile resident in `rd` (rows ty = wave, wave + 4) while the LDS-DMA of the
+// next tile lands in `dma`.  __restrict__ on purpose: see wgrad2.hip (keeps hipcc from
+// draining vmcnt before every LDS read).
+__device__ __forceinline__ void fw_step(const FirstWgradArgs& g, int m0, int wave, int lane, int next_tile,
+                                        char* __restrict__ dma, const char* __restrict__ rd,
+                                        const int (&xdesc)[10], int nxi, const int (&boff)[4], int NT, f32x4 (&acc)[4][4]) {
+    if (next_tile >= 0) fw_issue(g, m0, wave, lane, next_tile, dma, xdesc, nxi);
+    const int r16 = lane & 15, q = lane >> 4;
+    const float* hal = reinterpret_cast<const float*>(rd + FW_DY_BYTES);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ty = wave + 4 * kk;
+        // A: dy^T fragments of the four 16-channel M tiles, pixels 8q .. 8q+7 of row ty
+        u32x4 af[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            s16x4 h2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int tx = 8 * q + 4 * t + (r16 >> 2);
+                const int unit = m ^ fw_swz(tx);
+                h2[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4_t*)(rd + (ty * 32 + tx) * 128 + unit * 32 + (r16 & 3) * 8));
+            }
+            af[m] = __builtin_bit_cast(u32x4, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt < NT) {                                // wave-uniform
+                bf16x8 bfr;
+                const int base = boff[nt] + ty * 34 + 8 * q;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bfr[j] = (__bf16)(boff[nt] >= 0 ? hal[base + j] : 0.f);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), bfr, acc[m][nt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstWgradArgs g) {
+    __shared__ __attribute__((aligned(128))) char smem[2 * FW_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int split = blockIdx.x, m0 = blockIdx.y * 64;
+    const int C = g.C, NT = (9 * C + 15) >> 4;
+    const int nxi = (C * FW_HALO + 63) >> 6;             // 4-byte LDS-DMA wave-instructions for the halo
+
+    int xdesc[10];
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+        const int e = (it * 4 + wave) * 64 + lane;
+        const int c = e / FW_HALO, rr = e - c * FW_HALO;
+        const int hy = rr / 34, hx = rr - hy * 34;
+        xdesc[it] = c | (hy << 8) | (hx << 16) | ((c >= C ? 1 : 0) << 24);
+    }
+    // B column n = 16 nt + r16 = tap*C + c  ->  float offset of (c, dy, dx) in the halo, -1 if n >= 9C
+    int boff[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = nt * 16 + r16;
+        const int tap = n / C, c = n - tap * C, dy = tap / 3, dx = tap - dy * 3;
+        boff[nt] = n < 9 * C ? c * FW_HALO + dy * 34 + dx : -1;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[m][nt][j] = 0.f;
+
+    const int t_begin = split * g.tiles_per_split;
+    const int t_end = min(t_begin + g.tiles_per_split, g.ntiles);
+    if (t_begin < t_end) fw_issue(g, m0, wave, lane, t_begin, smem, xdesc, nxi);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int stage = (tile - t_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // tile landed; the other stage is free
+        fw_step(g, m0, wave, lane, tile + 1 < t_end ? tile + 1 : -1, smem + (stage ^ 1) * FW_STAGE, smem + stage * FW_STAGE,
+                xdesc, nxi, boff, NT, acc);
+    }
+    __syncthreads();
+    // sum the four waves: [wave][64 co][64 n] fp32 in LDS (64 KB)
+    float* ot = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ot[(wave * 64 + m * 16 + 4 * q + j) * 64 + nt * 16 + r16] = acc[m][nt][j];
+    __syncthreads();
+    float* dst = g.slab + ((long long)split * g.Cout + m0) * 64;
+    for (int i = tid; i < 64 * 64; i += 256) dst[i] = (ot[i] + ot[4096 + i]) + (ot[8192 + i] + ot[12288 + i]);
+}
+
+// out[co][c][tap] = sum over splits of slab[split][co][tap*C + c]
+__global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                                 int splits, int Cout, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * 9 * C) return;
+    const int tap = i % 9, c = (i / 9) % C, co = i / (9 * C);
+    const int n = tap * C + c;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += slab[((long long)sp * Cout + co) * 64 + n];
+    out[i] = s;
+}
+
+struct FwPlan { int tiles_x, tiles_y, ntiles, splits, tiles_per_split; };
+static FwPlan fw_plan(int N, int H, int W, int Cout) {
+    FwPlan p;
+    p.tiles_x = (W + 31) / 32; p.tiles_y = (H + 7) / 8;
+    p.ntiles = N * p.tiles_x * p.tiles_y;
+    int want = 1024 / (Cout / 64);
+    if (want < 1) want = 1;
+    if (want > p.ntiles) want = p.ntiles;
+    p.tiles_per_split = (p.ntiles + want - 1) / want;
+    p.splits = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
+    return p;
+}
+
+extern "C" size_t fea_first_wgrad_ws_bytes(int N, int H, int W, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 64) return 0;
+    FwPlan p = fw_plan(N, H, W, Cout);
+    return (size_t)p.splits * Cout * 64 * sizeof(float);
+}
+
+extern "C" int fea_conv3x3_first_wgrad(const void* dy, int lddy, const float* x, float* dW, void* ws, size_t ws_bytes,
+                                       int N, int C, int H, int W, int Cout, int dtype, void* stream) {
+    FEA_CHECK(dtype == FEA_BF16, FEA_E_UNSUPPORTED_SHAPE, "fea_conv3x3_first_wgrad: bf16 only (fp32: fea_conv1x1_im2col_wgrad)");
+    FEA_CHECK(dy && x && dW && ws, FEA_E_BADARG, "fea_conv3x3_first_wgrad: null pointer");
+    FEA_CHECK(N > 0 && H > 0 && W > 0 && C > 0 && 9 * C <= 64, FEA_E_UNSUPPORTED_SHAPE, "fea_conv3x3_first_wgrad: N=%d H=%d W=%d C=%d", N, H, W, C);
+    FEA_CHECK(Cout > 0 && Cout % 64 == 0 && lddy >= Cout && lddy % 8 == 0 && ((uintptr_t)dy % 16 == 0), FEA_E_BADARG,
+              "fea_conv3x3_first_wgrad: Cout=%d lddy=%d", Cout, lddy);
+    FEA_CHECK((long long)H * W * lddy < (1ll << 31) && (long long)C * H * W < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE,
+              "fea_conv3x3_first_wgrad: image too large");
+    FwPlan p = fw_plan(N, H, W, Cout);
+    const size_t need = (size_t)p.splits * Cout * 64 * sizeof(float);
+    FEA_CHECK(ws_bytes >= need, FEA_E_WORKSPACE, "fea_conv3x3_first_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+    FirstWgradArgs a{};
+    a.dy = (const __bf16*)dy; a.x = x; a.slab = (float*)ws; a.lddy = lddy; a.C = C; a.H = H; a.W = W; a.Cout = Cout;
+    a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(first_wgrad_kernel, dim3((unsigned)p.splits, (unsigned)(Cout / 64)), dim3(256), 0, s, a);
+    FEA_LAUNCH_CHECK();
+    const int total = Cout * 9 * C;
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       (const float*)ws, dW, p.splits, Cout, C);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}

@@ -13,6 +13,10 @@
 //   MODE 1  1x1: A rows = the tile's pixels.
 //   MODE 2  2x2 stride-2 gather (ConvTranspose2d data gradient): A row of pixel
 //           (i,j), tap (a,b) = input pixel (2i+a, 2j+b).
+//   MODE 3  first layer, bf16: 3x3 pad 1 over an fp32 NCHW input with few channels
+//           (K = 9*C <= 64).  The fp32 halo tile is staged in LDS and the im2col A
+//           fragments are gathered from it on the fly (no im2col tensor in HBM);
+//           the weight fragments live in registers.
 //   EPI 0   y[pixel][cout0+col] (+bias, + BatchNorm partial sums)
 //   EPI 1   pixel-shuffle store of ConvTranspose2d forward: GEMM column
 //           n = ab*Cup + co goes to pixel (2i+a, 2j+b), channel co.
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     constexpr int NDESC = MODE == 0 ? 1 : A_PASSES;
     int a_off[NDESC];
     unsigned a_valid = 0;
-    if (MODE != 0) {
+    if (MODE == 1 || MODE == 2) {
 #pragma unroll
         for (int i = 0; i < NDESC; ++i) {
             bool ok; a_off[i] = a_desc(i, ok);
@@ -414,6 +418,54 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
                 tap_mma(3 * t3, h0 + 6 * t3, std::integral_constant<int, 0>{});
                 tap_mma(3 * t3 + 1, h0 + 6 * t3 + 2, std::integral_constant<int, 2>{});
                 tap_mma(3 * t3 + 2, h0 + 6 * t3 + 4, std::integral_constant<int, 1>{});
+            }
+        }
+    } else if constexpr (MODE == 3) {
+        // g.x: fp32 [N,C,H,W]; g.Cin = C; k = tap*C + c; packed weights [ks][cout/16][lane][8]
+        constexpr int HW2 = TW + 2, HALO = (TH + 2) * HW2;
+        const int C = g.Cin;
+        const int KS = (9 * C + 31) >> 5;                  // 1 or 2 k-steps of 32
+        float* hal = reinterpret_cast<float*>(smem);
+        const float* __restrict__ xin = (const float*)g.x + (long long)n_img * g.x_img_stride;
+        for (int e = tid; e < C * HALO; e += 256) {
+            const int c = e / HALO, rr = e - c * HALO;
+            const int hy = rr / HW2, hx = rr - hy * HW2;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            hal[e] = ok ? xin[((long long)c * H + gy) * W + gx] : 0.f;
+        }
+        u32x4 Bf[2][4];
+        int koff[2][8];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int ksc = ks < KS ? ks : 0;
+                Bf[ks][n] = *reinterpret_cast<const u32x4*>(wg + (((long long)ksc * (g.Cout >> 4) + ((cout0 + wn * 64) >> 4) + n) * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = ks * 32 + q16 * 8 + j;
+                const int tap = k / C, c = k - tap * C;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                koff[ks][j] = k < 9 * C ? c * HALO + dy * HW2 + dx : -1;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT16; ++m) {
+            const int p = wm * (MT * 32) + m * 16 + r16;
+            const int pb = (p >> tws) * HW2 + (p & (TW - 1));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks < KS) {
+                    bf16x8 af;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) af[j] = (__bf16)(koff[ks][j] >= 0 ? hal[pb + koff[ks][j]] : 0.f);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc16[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, Bf[ks][n]), acc16[m][n], 0, 0, 0);
+                }
             }
         }
     } else if (MODE == 0 && BF) {
@@ -759,6 +811,22 @@ extern "C" int fea_conv3x3_dgrad_bnred(const void* dy, int lddy, const void* w_p
     a.ybn = y; a.ldybn = ldy_bn; a.bn_scale = scale; a.bn_shift = shift; a.bn_mean = save_mean; a.bn_invstd = save_invstd;
     a.red_part = part;
     return launch_igemm<__bf16, 0, 2>(a, N, (hipStream_t)stream);
+}
+
+extern "C" int fea_conv3x3_first(const float* x, const void* w_packed, const float* bias, void* y, int ldy, float* stats,
+                                 int N, int C, int H, int W, int Cout, int dtype, void* stream) {
+    FEA_CHECK(dtype == FEA_BF16, FEA_E_UNSUPPORTED_SHAPE, "fea_conv3x3_first: bf16 only (fp32: fea_im2col3x3_nchw + fea_conv1x1)");
+    FEA_CHECK(x && w_packed && y, FEA_E_BADARG, "fea_conv3x3_first: null pointer");
+    FEA_CHECK(N > 0 && H > 0 && W > 0, FEA_E_BADARG, "fea_conv3x3_first: bad dims");
+    FEA_CHECK(C > 0 && 9 * C <= 64, FEA_E_UNSUPPORTED_SHAPE, "fea_conv3x3_first: C=%d (9*C must be <= 64)", C);
+    FEA_CHECK(Cout > 0 && Cout % 64 == 0 && ldy >= Cout && ldy % 8 == 0, FEA_E_UNSUPPORTED_SHAPE, "fea_conv3x3_first: Cout=%d ldy=%d", Cout, ldy);
+    FEA_CHECK(((uintptr_t)y % 16 == 0) && ((uintptr_t)w_packed % 16 == 0) && ((uintptr_t)x % 4 == 0), FEA_E_BADARG, "fea_conv3x3_first: alignment");
+    FEA_CHECK((long long)H * W * ldy < (1ll << 31) && (long long)C * H * W < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "fea_conv3x3_first: image too large");
+    IgemmArgs a{};
+    a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.stats = stats;
+    a.ldx = 0; a.ldy = ldy; a.H = H; a.W = W; a.Cin = C; a.Cout = Cout; a.Cup = Cout;
+    a.x_img_stride = (long long)C * H * W; a.y_img_stride = (long long)H * W * ldy;
+    return launch_igemm<__bf16, 3, 0>(a, N, (hipStream_t)stream);
 }
 
 extern "C" int fea_conv1x1(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, float* stats,

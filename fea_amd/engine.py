@@ -63,7 +63,9 @@ class _Plan:
         self.N, self.H, self.W = N, H, W
         self.dims = [(H >> l, W >> l) for l in range(5)]
         es = torch.empty
-        self.xcol = es((N, H, W, eng.kpad), dtype=dt, device=dev)
+        # im2col rows of the input: only the generic first-layer path needs them
+        self.xcol = None if eng.first_direct else es((N, H, W, eng.kpad), dtype=dt, device=dev)
+        self.x_in = None
         self.y: Dict[str, torch.Tensor] = {}
         self.a0: Dict[str, torch.Tensor] = {}
         self.a3: Dict[str, torch.Tensor] = {}
@@ -118,7 +120,8 @@ class _Plan:
             c = CH[blk]
             cin0 = eng.block_cin(blk)
             if blk == "enc1":
-                ws = max(ws, lib.fea_wgrad_ws_bytes(1, N, h, w, c, eng.kpad, code))
+                ws = max(ws, lib.fea_first_wgrad_ws_bytes(N, h, w, c) if eng.first_direct
+                         else lib.fea_wgrad_ws_bytes(1, N, h, w, c, eng.kpad, code))
             else:
                 ws = max(ws, lib.fea_wgrad_ws_bytes(0, N, h, w, c, cin0, code))
             ws = max(ws, lib.fea_wgrad_ws_bytes(0, N, h, w, c, c, code))
@@ -147,6 +150,9 @@ class UNetEngine:
         self.in_channels = module.in_channels
         self.num_classes = module.num_classes
         self.kpad = (9 * self.in_channels + KPAD_ALIGN - 1) // KPAD_ALIGN * KPAD_ALIGN
+        # bf16 and 9*C <= 64: the first layer reads the fp32 NCHW input directly
+        # (fea_conv3x3_first / _first_wgrad); otherwise im2col rows + 1x1 GEMM
+        self.first_direct = compute_dtype == torch.bfloat16 and 9 * self.in_channels <= 64
         self.device = None
         self.plans: Dict[tuple, _Plan] = {}
         self.packed: Dict[str, torch.Tensor] = {}
@@ -229,6 +235,9 @@ class UNetEngine:
 
     def _w_fwd(self, name: str):
         p = self._params()[name + ".weight"]
+        if name == "enc1.0" and self.first_direct:
+            ks = (9 * self.in_channels + 31) // 32
+            return self._pack(name + "/f", p, ks * 64 * 32, "fea_pack_conv3x3_first", 64, self.in_channels)
         if name == "enc1.0":
             return self._pack(name + "/f", p, 64 * self.kpad, "fea_pack_conv3x3_im2col", 64, self.in_channels, self.kpad)
         co, ci = p.shape[0], p.shape[1]
@@ -264,7 +273,9 @@ class UNetEngine:
         code = self.code
         taps = self.debug_taps
 
-        L.call("fea_im2col3x3_nchw", x, pl.xcol, N, self.in_channels, H, W, self.kpad, code, S)
+        pl.x_in = x
+        if not self.first_direct:
+            L.call("fea_im2col3x3_nchw", x, pl.xcol, N, self.in_channels, H, W, self.kpad, code, S)
 
         def conv_bn(name, inp, ld_in, cin, h, w, cout, out_full, ld_full, out_pool):
             """conv -> BN statistics -> scale/shift -> ReLU(+pool)"""
@@ -272,7 +283,9 @@ class UNetEngine:
             stats = pl.stats if training else None
             wp = self._w_fwd(name)
             bias = P[name + ".bias"]
-            if name == "enc1.0":
+            if name == "enc1.0" and self.first_direct:
+                L.call("fea_conv3x3_first", pl.x_in, wp, bias, y, cout, stats, N, self.in_channels, h, w, cout, code, S)
+            elif name == "enc1.0":
                 L.call("fea_conv1x1", inp, ld_in, wp, bias, y, cout, stats, N, h, w, self.kpad, cout, code, S)
             else:
                 L.call("fea_conv3x3", inp, ld_in, wp, bias, y, cout, stats, N, h, w, cin, cout, code, S)
@@ -400,7 +413,10 @@ class UNetEngine:
             else:
                 L.call("fea_conv3x3", pl.dY, c, self._w_dgrad(n3), None, pl.gmid, c, None, N, h, w, c, c, code, S)
                 bn_bwd(n0, pl.gmid, c, None, h, w, c)
-            if blk == "enc1":
+            if blk == "enc1" and self.first_direct:
+                L.call("fea_conv3x3_first_wgrad", pl.dY, c, pl.x_in, g[n0 + ".weight"], pl.ws, pl.ws_bytes,
+                       N, self.in_channels, h, w, c, code, S)
+            elif blk == "enc1":
                 L.call("fea_conv1x1_im2col_wgrad", pl.dY, c, pl.xcol, self.kpad, g[n0 + ".weight"], pl.ws, pl.ws_bytes,
                        N, h, w, self.kpad, self.in_channels, c, code, S)
             else:

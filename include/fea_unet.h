@@ -73,6 +73,18 @@ int fea_pack_conv3x3_im2col(const float* w, void* out, int Co, int C, int Kpad, 
  * bwd-data: out[ab*(Co/CK)+chunk][ci][j] = w[ci][chunk*CK+j][a][b] (GEMM N = Ci)  */
 int fea_pack_upconv2x2(const float* w, void* out, int Ci, int Co, int bwd, int dtype, void* stream);
 
+/* First layer, bf16 fast path: enc1[0] = Conv2d(in_channels,64,3,padding=1) (models.py:10,28)
+ * straight from the fp32 NCHW input (9*C <= 64): the im2col gather happens inside the kernel.
+ * Pack: out[ks][co/16][lane][8] bf16, (9C+31)/32 * Co * 32 elements. */
+int fea_pack_conv3x3_first(const float* w, void* out, int Co, int C, int dtype, void* stream);
+int fea_conv3x3_first(const float* x_nchw, const void* w_packed, const float* bias, void* y, int ldy, float* stats,
+                      int N, int C, int H, int W, int Cout, int dtype, void* stream);
+/* its weight gradient: dW[co,c,3,3] = sum_p dy[p,co] x[p+tap,c] from dy NHWC bf16 and x fp32 NCHW.
+ * ws: fp32 workspace of fea_first_wgrad_ws_bytes() bytes. */
+size_t fea_first_wgrad_ws_bytes(int N, int H, int W, int Cout);
+int fea_conv3x3_first_wgrad(const void* dy, int lddy, const float* x_nchw, float* dW, void* ws, size_t ws_bytes,
+                            int N, int C, int H, int W, int Cout, int dtype, void* stream);
+
 /* ---- implicit-GEMM convolutions (MFMA) ----------------------------------- */
 
 /* y = conv3x3(x, w_packed) + bias          models.py:28,31 (forward) and the

@@ -159,6 +159,46 @@ def test_conv3x3_wgrad(dt, shape):
     check(dW, ref, dt, "conv3x3 wgrad", scale=0.5 if dt == torch.bfloat16 else 1.0)
 
 
+@pytest.mark.parametrize("cin", [3, 1, 5, 7])
+@pytest.mark.parametrize("hw", [(32, 48), (16, 16), (40, 72)])
+def test_first_layer_direct_path(cin, hw):
+    """enc1.0 = Conv2d(in_channels, 64, 3, padding=1) straight from the fp32 NCHW input (bf16
+    path): forward + BN partial sums + weight gradient against F.conv2d on bf16-rounded inputs."""
+    dt = torch.bfloat16
+    code = L.dt_code(dt)
+    n, (h, w), co = 2, hw, 64
+    g = torch.Generator().manual_seed(13)
+    x = rnd(dt, n, cin, h, w, gen=g)                      # representable in bf16: both sides see the same values
+    wt = (rnd(dt, co, cin, 3, 3, gen=g) / (3 * cin ** 0.5)).to(dt).float()
+    bias = torch.randn(co, generator=g)
+    ref = F.conv2d(x, wt, bias, padding=1)
+    ks = (9 * cin + 31) // 32
+    wp = torch.empty(ks * co * 32, dtype=dt, device=DEV)
+    L.call("fea_pack_conv3x3_first", wt.to(DEV), wp, co, cin, code, S())
+    ntiles = L.call("fea_conv_num_tiles", n, h, w)
+    stats = torch.full((ntiles, co, 2), float("nan"), device=DEV)
+    y = torch.full((n, h, w, co + 64), float("nan"), dtype=dt, device=DEV)
+    xd = x.to(DEV).contiguous()
+    L.call("fea_conv3x3_first", xd, wp, bias.to(DEV), view_ptr(y, 64), co + 64, stats, n, cin, h, w, co, code, S())
+    torch.cuda.synchronize()
+    check(from_nhwc(y, co, 64), ref, dt, "first-layer conv")
+    assert torch.isnan(y[..., :64].float()).all(), "wrote outside its channel slice"
+    s = stats.double().sum(0).cpu()
+    ref_s = torch.stack([ref.double().sum((0, 2, 3)), (ref.double() ** 2).sum((0, 2, 3))], 1)
+    assert rel_l2(s, ref_s) < 1e-5, "BN partial sums"
+    # weight gradient
+    dy = rnd(dt, n, co, h, w, gen=g)
+    wz = torch.zeros(co, cin, 3, 3, requires_grad=True)
+    F.conv2d(x, wz, padding=1).backward(dy)
+    nbytes = L.load().fea_first_wgrad_ws_bytes(n, h, w, co)
+    ws = torch.empty(nbytes // 4, device=DEV)
+    dW = torch.full((co, cin, 3, 3), float("nan"), device=DEV)
+    dyd = to_nhwc(dy, dt, ld=co + 128, off=128)
+    L.call("fea_conv3x3_first_wgrad", view_ptr(dyd, 128), co + 128, xd, dW, ws, nbytes, n, cin, h, w, co, code, S())
+    torch.cuda.synchronize()
+    check(dW, wz.grad, dt, "first-layer wgrad", scale=0.5)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cin", [3, 1, 5])
 def test_enc1_im2col_path(dt, cin):
