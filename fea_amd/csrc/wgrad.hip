@@ -274,8 +274,15 @@ size_t fea_wgrad2_ws_bytes(int N, int H, int W, int Cm, int Cn);
 int fea_wgrad2_launch(const void* dy, int lddy, const void* x, int ldx, float* dW, void* ws, size_t ws_bytes,
                       int N, int H, int W, int Cin, int Cout, hipStream_t s);
 
+// bf16 ConvTranspose2d path: wgrad_up.hip
+bool fea_wgrad_up_supported(int Cin, int Cout, int dtype);
+size_t fea_wgrad_up_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int fea_wgrad_up_launch(const void* x, int ldx, const void* dy, int lddy, float* dW, void* ws, size_t ws_bytes,
+                        int N, int H, int W, int Cin, int Cout, hipStream_t s);
+
 extern "C" size_t fea_wgrad_ws_bytes(int mode, int N, int H, int W, int Cm, int Cn, int dtype) {
     if (N <= 0 || H <= 0 || W <= 0 || Cm <= 0 || Cn <= 0 || Cm % 64 || Cn % 64) return 0;
+    if (mode == 2 && fea_wgrad_up_supported(Cm, Cn, dtype)) { const size_t b = fea_wgrad_up_ws_bytes(N, H, W, Cm, Cn); return b ? b : 256; }
     if (mode == 0 && dtype == FEA_BF16) { const size_t b = fea_wgrad2_ws_bytes(N, H, W, Cm, Cn); return b ? b : 256; }
     WgradPlan p = wgrad_plan(mode, N, H, W, Cm, Cn, dtype);
     return (size_t)p.splits * p.ntaps * Cm * Cn * sizeof(float);
@@ -303,6 +310,8 @@ static int wgrad_common(int mode, const void* P, int ldp, const void* Q, int ldq
     FEA_CHECK(p_img < (1ll << 31) && q_img < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "%s: image too large", who);
     if (mode == 0 && dtype == FEA_BF16)
         return fea_wgrad2_launch(P, ldp, Q, ldq, dW, ws, ws_bytes, N, H, W, Nn, M, (hipStream_t)stream);
+    if (mode == 2 && fea_wgrad_up_supported(M, Nn, dtype))
+        return fea_wgrad_up_launch(P, ldp, Q, ldq, dW, ws, ws_bytes, N, H, W, M, Nn, (hipStream_t)stream);
     WgradPlan p = wgrad_plan(mode, N, H, W, M, Nn, dtype);
     const size_t need = (size_t)p.splits * p.ntaps * M * Nn * sizeof(float);
     FEA_CHECK(ws_bytes >= need, FEA_E_WORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
