@@ -188,8 +188,41 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// Partial-sum tables with very many rows (one row per conv pixel tile: 65,536 at 512x512,
+// batch 64) are folded IN PLACE before the per-channel finalize kernels: block b adds rows
+// [b*rpb, (b+1)*rpb) with coalesced row reads (double accumulation) and stores the result
+// into its own first row, so the finalize kernels read `nb` rows at stride rpb.
+__global__ __launch_bounds__(256) void fold_rows_kernel(float* __restrict__ part, int nrows, int ldf, int rpb) {
+    __shared__ double red[256];
+    const int L = ldf < 256 ? ldf : 256, slots = 256 / L;
+    const int cl = threadIdx.x % L, slot = threadIdx.x / L;
+    const int r0 = blockIdx.x * rpb, r1 = min(r0 + rpb, nrows);
+    for (int c0 = 0; c0 < ldf; c0 += 256) {
+        const int col = c0 + cl;
+        double a = 0.0;
+        if (slot < slots && col < ldf)
+            for (int r = r0 + slot; r < r1; r += slots) a += (double)part[(long long)r * ldf + col];
+        __syncthreads();                          // every read of row r0 is done before it is overwritten
+        red[threadIdx.x] = a;
+        __syncthreads();
+        if (slot == 0 && col < ldf) {
+            double t = 0.0;
+            for (int sl = 0; sl < slots; ++sl) t += red[sl * L + cl];
+            part[(long long)r0 * ldf + col] = (float)t;
+        }
+    }
+}
+static void fold_rows(float* part, int& nrows, int& rstride, int ldf, hipStream_t s) {
+    rstride = 1;
+    if (nrows < 4096 || ldf % 2 || (ldf > 256 && ldf % 256)) return;
+    const int nb = 256, rpb = (nrows + nb - 1) / nb;
+    const int nfold = (nrows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(fold_rows_kernel, dim3(nfold), dim3(256), 0, s, part, nrows, ldf, rpb);
+    nrows = nfold; rstride = rpb;
+}
+
 // one block per channel
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int ntiles, long long count,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int ntiles, int rstride, long long count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, float momentum, float eps,
                                                           float* scale, float* shift, float* save_mean, float* save_invstd, int C) {
@@ -197,7 +230,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
     for (int t = threadIdx.x; t < ntiles; t += 256) {
-        const float2 v = *reinterpret_cast<const float2*>(stats + ((long long)t * C + c) * 2);
+        const float2 v = *reinterpret_cast<const float2*>(stats + ((long long)t * rstride * C + c) * 2);
         s += v.x; q += v.y;
     }
     s = block_sum_d(s, sh);
@@ -403,14 +436,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const T* __restrict__ 
 }
 
 // one block per channel: dgamma, dbeta, coef
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, long long count,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int rstride, long long count,
                                                               const float* __restrict__ gamma, const float* __restrict__ save_invstd,
                                                               float* dgamma, float* dbeta, float* coef, int C) {
     __shared__ double sh[4];
     const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
     for (int t = threadIdx.x; t < nblk; t += 256) {
-        const float2 v = *reinterpret_cast<const float2*>(part + ((long long)t * C + c) * 2);
+        const float2 v = *reinterpret_cast<const float2*>(part + ((long long)t * rstride * C + c) * 2);
         s += v.x; q += v.y;
     }
     s = block_sum_d(s, sh);
@@ -423,12 +456,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
 }
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk, int C, int slot,
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk, int rstride, int C, int slot,
                                                               float* __restrict__ out) {
     __shared__ double sh[4];
     const int c = blockIdx.x;
     double s = 0.0;
-    for (int t = threadIdx.x; t < nblk; t += 256) s += part[((long long)t * C + c) * 2 + slot];
+    for (int t = threadIdx.x; t < nblk; t += 256) s += part[((long long)t * rstride * C + c) * 2 + slot];
     s = block_sum_d(s, sh);
     if (threadIdx.x == 0) out[c] = (float)s;
 }
@@ -549,7 +582,9 @@ extern "C" int fea_bn_finalize(const float* stats, int ntiles, long long count, 
     FEA_CHECK(stats && gamma && beta && scale && shift && save_mean && save_invstd && ntiles > 0 && count > 0 && C > 0,
               FEA_E_BADARG, "fea_bn_finalize: bad args");
     FEA_CHECK((running_mean == nullptr) == (running_var == nullptr), FEA_E_BADARG, "fea_bn_finalize: running stats must both be given");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, ntiles, count, gamma, beta,
+    int rstride;
+    fold_rows(const_cast<float*>(stats), ntiles, rstride, C * 2, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, ntiles, rstride, count, gamma, beta,
                        running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd, C);
     FEA_LAUNCH_CHECK();
     return FEA_OK;
@@ -651,7 +686,9 @@ extern "C" int fea_bn_bwd_finalize(const float* part, int nblk, long long count,
                                    float* dgamma, float* dbeta, float* coef, int C, void* stream) {
     FEA_CHECK(part && gamma && save_invstd && dgamma && dbeta && coef && nblk > 0 && count > 0 && C > 0, FEA_E_BADARG,
               "fea_bn_bwd_finalize: bad args");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, nblk, count, gamma, save_invstd,
+    int rstride;
+    fold_rows(const_cast<float*>(part), nblk, rstride, C * 2, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, nblk, rstride, count, gamma, save_invstd,
                        dgamma, dbeta, coef, C);
     FEA_LAUNCH_CHECK();
     return FEA_OK;
@@ -659,7 +696,9 @@ extern "C" int fea_bn_bwd_finalize(const float* part, int nblk, long long count,
 
 extern "C" int fea_reduce_partials(const float* part, int nblk, int C, int slot, float* out, void* stream) {
     FEA_CHECK(part && out && nblk > 0 && C > 0 && (slot == 0 || slot == 1), FEA_E_BADARG, "fea_reduce_partials: bad args");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, nblk, C, slot, out);
+    int rstride;
+    fold_rows(const_cast<float*>(part), nblk, rstride, C * 2, (hipStream_t)stream);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, nblk, rstride, C, slot, out);
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }
@@ -667,7 +706,9 @@ extern "C" int fea_reduce_partials(const float* part, int nblk, int C, int slot,
 extern "C" int fea_reduce_partials_n(const float* part, int nblk, int ld, int n, int slot, float* out, void* stream) {
     FEA_CHECK(part && out && nblk > 0 && ld > 0 && n > 0 && n <= ld && (slot == 0 || slot == 1), FEA_E_BADARG,
               "fea_reduce_partials_n: bad args");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, part, nblk, ld, slot, out);
+    int rstride;
+    fold_rows(const_cast<float*>(part), nblk, rstride, ld * 2, (hipStream_t)stream);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, part, nblk, rstride, ld, slot, out);
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }

@@ -15,6 +15,10 @@
  *    passed as void*; NULL = the default stream).  The caller owns every
  *    buffer, including workspaces, and keeps them alive until the stream work
  *    has completed.
+ *  - partial-sum tables (`stats`, `part`) are scratch: the functions that reduce them
+ *    (fea_bn_finalize, fea_bn_bwd_finalize, fea_reduce_partials[_n]) may fold rows in
+ *    place (tables of >= 4096 rows), so a table is CONSUMED by the first call that reduces it:
+ *    reduce each table once.
  *  - `dtype` is FEA_F32 or FEA_BF16: the storage type of activations and
  *    packed weights.  Accumulation is always fp32.  Parameters, gradients,
  *    BatchNorm statistics and logits are always fp32.

@@ -422,3 +422,27 @@ def test_bad_arguments_are_rejected():
         L.call("fea_head_fwd", x, 64, x, x, x, 1, 8, 8, 64, 17, L.F32, S())                    # too many classes
     with pytest.raises(L.FeaError):
         L.call("fea_conv3x3_wgrad", x, 64, x, 64, x, x, 16, 1, 8, 8, 64, 64, L.F32, S())      # workspace too small
+
+
+def test_large_partial_tables_are_folded_correctly():
+    """>= 4096 rows: fea_bn_finalize / fea_reduce_partials_n fold the table in place first."""
+    g = torch.Generator().manual_seed(21)
+    rows, c = 5000, 64
+    stats = torch.rand(rows, c, 2, generator=g)
+    count = rows * 256
+    s = stats.double().sum(0)
+    mean = s[:, 0] / count
+    var = (s[:, 1] / count - mean * mean).clamp(min=0)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    outs = [torch.empty(c, device=DEV) for _ in range(4)]
+    L.call("fea_bn_finalize", stats.to(DEV), rows, count, gamma.to(DEV), beta.to(DEV), None, None, 0.1, 1e-5, *outs, c, S())
+    torch.cuda.synchronize()
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    assert rel_l2(outs[2], mean.float()) < 1e-6 and rel_l2(outs[3], invstd.float()) < 1e-6
+    assert rel_l2(outs[0], (gamma.double() * invstd).float()) < 1e-6
+    # first 32 channels of 128-channel-wide rows
+    part = torch.rand(rows, 128, 2, generator=g)
+    out = torch.empty(32, device=DEV)
+    L.call("fea_reduce_partials_n", part.to(DEV), rows, 128, 32, 0, out, S())
+    torch.cuda.synchronize()
+    assert rel_l2(out, part[:, :32, 0].double().sum(0).float()) < 1e-6
