@@ -180,7 +180,7 @@ static FwPlan fw_plan(int N, int H, int W, int Cout) {
     FwPlan p;
     p.tiles_x = (W + 31) / 32; p.tiles_y = (H + 7) / 8;
     p.ntiles = N * p.tiles_x * p.tiles_y;
-    int want = 1024 / (Cout / 64);
+    int want = 512 / (Cout / 64);
     if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
     p.tiles_per_split = (p.ntiles + want - 1) / want;

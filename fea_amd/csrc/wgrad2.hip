@@ -294,7 +294,7 @@ static Wgrad2Plan wgrad2_plan(int N, int H, int W, int M, int Nn) {
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH;
     p.ntiles = N * p.tiles_x * p.tiles_y;
     p.nmt = M / 64; p.nnt = Nn / 64;
-    int want = 1024 / (p.nmt * p.nnt);               // ~4 workgroups per CU over the launch
+    int want = 256 / (p.nmt * p.nnt);                // one workgroup per CU: fewest slabs to write and re-read
     if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
     p.tiles_per_split = (p.ntiles + want - 1) / want;

@@ -151,7 +151,7 @@ static WuPlan wu_plan(int N, int H, int W, int Cin, int Cout) {
     p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 3) / 4;
     p.ntiles = N * p.tiles_x * p.tiles_y;
     p.nmt = Cin / 128; p.nnt = Cout / 64;
-    int want = 1024 / (p.nmt * p.nnt);
+    int want = 256 / (p.nmt * p.nnt);
     if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
     p.tiles_per_split = (p.ntiles + want - 1) / want;
