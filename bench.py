@@ -116,29 +116,46 @@ def main():
         dt = float(t.item())
     loss_val = float(loss.item())
 
-    # live per-kernel timing (HIP events on the launch stream) of the dominant kernel
+    # live per-kernel timing (HIP events on the launch stream, = torch's current stream)
     roof = None
     if rank == 0 and not a.no_kernel_timing:
+        NREP = 3
         L.PROFILE = []
-        for _ in range(2):
+        for _ in range(NREP):
             trainer.step(x, tgt)
         torch.cuda.synchronize()
         prof, L.PROFILE = L.PROFILE, None
         per = {}
+        dom = [0.0, 0, 0.0]                     # dominant kernel: ms, launches, flops
         for name, e0, e1, args in prof:
             ms = e0.elapsed_time(e1)
             d = per.setdefault(name, [0.0, 0, 0.0])
             d[0] += ms
             d[1] += 1
+            fl = 0.0
             if name == "fea_conv3x3":
-                d[2] += conv_flops(args)
-        ms, cnt, fl = per["fea_conv3x3"]
+                fl = conv_flops(args)
+                cout, wdt = args[11], args[9]
+                # igemm_kernel<bf16, MODE 0, BN 128, EPI 0, TWS 5>: Cout % 128 == 0 and W >= 32
+                if cout % 128 == 0 and wdt >= 32:
+                    dom[0] += ms; dom[1] += 1; dom[2] += fl
+            elif name == "fea_conv3x3_dgrad_bnred":
+                n, h, w, cin, cout = args[12:17]
+                fl = 2.0 * n * h * w * cin * cout * 9
+            elif name == "fea_conv3x3_wgrad":
+                n, h, w, cin, cout = args[7:12]
+                fl = 2.0 * n * h * w * cin * cout * 9
+            d[2] += fl
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
-        ach = fl / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "igemm_kernel (fea_conv3x3: conv3x3 forward + dgrad launches)",
+        ach = dom[2] / (dom[0] * 1e-3) / 1e12
+        roof = {"bound": "mfma",
+                "kernel": "igemm_kernel<bf16, MODE 0 (3x3), 128 columns, EPI 0, 8x32 tile> = fea_conv3x3 launches with Cout % 128 == 0 "
+                          "(forward and data-gradient convolutions)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                "avg_launch_ms": ms / cnt, "launches_per_step": cnt // 2,
-                "kernel_ms_per_step": {k: v[0] / 2 for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])}}
+                "avg_launch_ms": dom[0] / dom[1], "launches_per_step": dom[1] // NREP,
+                "algorithmic_flop_per_launch": "2*N*H*W*Cin*Cout*9 (summed over the launches)",
+                "mfma_kernels_tflops": {k: v[2] / (v[0] * 1e-3) / 1e12 for k, v in per.items() if v[2] > 0},
+                "kernel_ms_per_step": {k: v[0] / NREP for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])}}
 
     if rank == 0:
         ips = world * a.batch * a.steps / dt
