@@ -17,11 +17,15 @@ Data layout in HBM (N = batch, level l has spatial H/2^l x W/2^l):
   a[dec_k.3], a[bottleneck.3]         dense
   dcat[k]         like cat[k]         gradient of the concat buffer (skip half lives until
                                       the encoder backward reaches level k)
-  G0,G1,gmid,dY   N*H*W*64 elements   rotating gradient buffers
+  G0,G1,gmid      N*H*W*64 elements   rotating gradient buffers
+  dY[0..2]        N*H*W*64 elements   ring of conv-output gradients: the weight-gradient
+                                      kernels read them on a second stream while the main
+                                      stream carries on with dgrad / BatchNorm backward
 """
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -108,7 +112,9 @@ class _Plan:
         big = N * H * W * 64
         self.G = [es(big, dtype=dt, device=dev) for _ in range(2)]
         self.gmid = es(big, dtype=dt, device=dev)
-        self.dY = es(big, dtype=dt, device=dev)
+        self.dYs = [es(big, dtype=dt, device=dev) for _ in range(3)]
+        self.dY_free = [None, None, None]     # event: the wgrad that read this slot has run
+        self.dY_next = 0
         for k, blk in enumerate(ENC, start=1):
             h, w = self.dims[k - 1]
             self.dcat[k] = es((N, h, w, 2 * CH[blk]), dtype=dt, device=dev)
@@ -171,6 +177,10 @@ class UNetEngine:
         # the module leaves eval mode, a parameter's version/storage changes or
         # invalidate() is called.
         self._gen = 0
+        # Weight-gradient kernels (MFMA-bound, one workgroup per CU) run on their own stream so
+        # that the HBM-bound BatchNorm-backward kernels of the following layers overlap them.
+        self.overlap_wgrad = os.environ.get("FEA_AMD_WGRAD_STREAM", "1") != "0"
+        self._wstream = None
         L.load()
 
     # ------------------------------------------------------------------ utils
@@ -376,6 +386,43 @@ class UNetEngine:
                 for n in names:
                     self.grad_ready(n)
 
+        main = torch.cuda.current_stream()
+        side = None
+        if self.overlap_wgrad and L.PROFILE is None:      # per-call timing wants one stream
+            if self._wstream is None or self._wstream.device != self.device:
+                self._wstream = torch.cuda.Stream(device=self.device)
+            side = self._wstream
+        ring = {"dY": pl.dYs[0], "slot": 0}
+
+        def next_dY():
+            """Next slot of the dY ring (waits until the wgrad that last read it has run)."""
+            i = pl.dY_next
+            pl.dY_next = (i + 1) % len(pl.dYs)
+            if pl.dY_free[i] is not None:
+                main.wait_event(pl.dY_free[i])
+                pl.dY_free[i] = None
+            ring["dY"], ring["slot"] = pl.dYs[i], i
+            return pl.dYs[i]
+
+        def wgrad(fn, args_before_stream, names, reads_dY=True):
+            """Enqueue a weight-gradient kernel (second stream when overlapping) and report
+            `names` ready behind it.  Everything enqueued on the main stream so far (the dY it
+            reads, the bias / BatchNorm gradients in `names`) is ordered before it."""
+            if side is None:
+                L.call(fn, *args_before_stream, S)
+                done(*names)
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                L.call(fn, *args_before_stream, side.cuda_stream)
+                if reads_dY:
+                    fe = torch.cuda.Event()
+                    fe.record(side)
+                    pl.dY_free[ring["slot"]] = fe
+                done(*names)
+
         fuse = self.dtype == torch.bfloat16     # dgrad kernels also produce the next BN-backward's partial sums
 
         def bn_bwd(name, da_full, ld_da, dpool, h, w, c, reduced_tiles=0):
@@ -386,6 +433,7 @@ class UNetEngine:
             cf = pl.coef[name]
             y = pl.y[name]
             nblk = L.call("fea_bn_bwd_blocks", N, h, w, c)
+            dY = next_dY()
             if reduced_tiles:
                 nfin = reduced_tiles
             else:
@@ -395,7 +443,7 @@ class UNetEngine:
             L.call("fea_bn_bwd_finalize", pl.part, nfin, N * h * w, P[bn + ".weight"], cf["invstd"],
                    g[bn + ".weight"], g[bn + ".bias"], pl.bncoef, c, S)
             L.call("fea_bn_relu_bwd_apply", da_full, ld_da, dpool, y, cf["scale"], cf["shift"], cf["mean"], cf["invstd"],
-                   pl.bncoef, pl.dY, pl.part, N, h, w, c, code, S)
+                   pl.bncoef, dY, pl.part, N, h, w, c, code, S)
             L.call("fea_reduce_partials", pl.part, nblk, c, 0, g[name + ".bias"], S)
 
         def block_bwd(blk, da_full, ld_da, dpool, inp, ld_in, cin, d_in, ld_din, din_stats=None):
@@ -403,27 +451,27 @@ class UNetEngine:
             c = CH[blk]
             n3, n0 = f"{blk}.3", f"{blk}.0"
             bn_bwd(n3, da_full, ld_da, dpool, h, w, c)
-            L.call("fea_conv3x3_wgrad", pl.dY, c, pl.a0[blk], c, g[n3 + ".weight"], pl.ws, pl.ws_bytes, N, h, w, c, c, code, S)
-            done(n3 + ".weight", n3 + ".bias", f"{blk}.4.weight", f"{blk}.4.bias")
+            wgrad("fea_conv3x3_wgrad", (ring["dY"], c, pl.a0[blk], c, g[n3 + ".weight"], pl.ws, pl.ws_bytes, N, h, w, c, c, code),
+                  (n3 + ".weight", n3 + ".bias", f"{blk}.4.weight", f"{blk}.4.bias"))
             if fuse:
                 cf0 = pl.coef[n0]
-                L.call("fea_conv3x3_dgrad_bnred", pl.dY, c, self._w_dgrad(n3), pl.gmid, c, pl.y[n0], c,
+                L.call("fea_conv3x3_dgrad_bnred", ring["dY"], c, self._w_dgrad(n3), pl.gmid, c, pl.y[n0], c,
                        cf0["scale"], cf0["shift"], cf0["mean"], cf0["invstd"], pl.part, N, h, w, c, c, code, S)
                 bn_bwd(n0, pl.gmid, c, None, h, w, c, reduced_tiles=L.call("fea_conv_num_tiles", N, h, w))
             else:
-                L.call("fea_conv3x3", pl.dY, c, self._w_dgrad(n3), None, pl.gmid, c, None, N, h, w, c, c, code, S)
+                L.call("fea_conv3x3", ring["dY"], c, self._w_dgrad(n3), None, pl.gmid, c, None, N, h, w, c, c, code, S)
                 bn_bwd(n0, pl.gmid, c, None, h, w, c)
+            names0 = (n0 + ".weight", n0 + ".bias", f"{blk}.1.weight", f"{blk}.1.bias")
             if blk == "enc1" and self.first_direct:
-                L.call("fea_conv3x3_first_wgrad", pl.dY, c, pl.x_in, g[n0 + ".weight"], pl.ws, pl.ws_bytes,
-                       N, self.in_channels, h, w, c, code, S)
+                wgrad("fea_conv3x3_first_wgrad", (ring["dY"], c, pl.x_in, g[n0 + ".weight"], pl.ws, pl.ws_bytes,
+                                                  N, self.in_channels, h, w, c, code), names0)
             elif blk == "enc1":
-                L.call("fea_conv1x1_im2col_wgrad", pl.dY, c, pl.xcol, self.kpad, g[n0 + ".weight"], pl.ws, pl.ws_bytes,
-                       N, h, w, self.kpad, self.in_channels, c, code, S)
+                wgrad("fea_conv1x1_im2col_wgrad", (ring["dY"], c, pl.xcol, self.kpad, g[n0 + ".weight"], pl.ws, pl.ws_bytes,
+                                                   N, h, w, self.kpad, self.in_channels, c, code), names0)
             else:
-                L.call("fea_conv3x3_wgrad", pl.dY, c, inp, ld_in, g[n0 + ".weight"], pl.ws, pl.ws_bytes, N, h, w, cin, c, code, S)
-            done(n0 + ".weight", n0 + ".bias", f"{blk}.1.weight", f"{blk}.1.bias")
+                wgrad("fea_conv3x3_wgrad", (ring["dY"], c, inp, ld_in, g[n0 + ".weight"], pl.ws, pl.ws_bytes, N, h, w, cin, c, code), names0)
             if d_in is not None:
-                L.call("fea_conv3x3", pl.dY, c, self._w_dgrad(n0), None, d_in, ld_din, din_stats, N, h, w, c, cin, code, S)
+                L.call("fea_conv3x3", ring["dY"], c, self._w_dgrad(n0), None, d_in, ld_din, din_stats, N, h, w, c, cin, code, S)
 
         # head
         nblk = L.call("fea_head_bwd_blocks", N, H, W)
@@ -441,9 +489,8 @@ class UNetEngine:
             src = pl.a3[f"dec{k + 1}"] if k < 4 else pl.a3["bottleneck"]
             L.call("fea_reduce_partials_n", pl.stats, L.call("fea_conv_num_tiles", N, 2 * hl, 2 * wl), 2 * c, c, 0,
                    g[f"upconv{k}.bias"], S)
-            L.call("fea_upconv2x2_wgrad", src, 2 * c, pl.dcat[k], 2 * c, g[f"upconv{k}.weight"], pl.ws, pl.ws_bytes,
-                   N, hl, wl, 2 * c, c, code, S)
-            done(f"upconv{k}.weight", f"upconv{k}.bias")
+            wgrad("fea_upconv2x2_wgrad", (src, 2 * c, pl.dcat[k], 2 * c, g[f"upconv{k}.weight"], pl.ws, pl.ws_bytes,
+                                          N, hl, wl, 2 * c, c, code), (f"upconv{k}.weight", f"upconv{k}.bias"), reads_dY=False)
             L.call("fea_upconv2x2_bwd_data", pl.dcat[k], 2 * c, self._w_up(f"upconv{k}", 1), pl.G[0], 2 * c,
                    N, hl, wl, 2 * c, c, code, S)
         # bottleneck and encoder
@@ -458,4 +505,8 @@ class UNetEngine:
             else:
                 block_bwd(blk, off_ptr(pl.dcat[k], c), 2 * c, pl.G[cur], pl.xcol, self.kpad, self.kpad, None, 0)
             cur = 1 - cur
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            main.wait_event(ev)
         return g
