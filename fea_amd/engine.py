@@ -102,6 +102,10 @@ class _Plan:
                 self.coef[f"{blk}.{idx}"] = {k: es(c, dtype=torch.float32, device=dev)
                                              for k in ("scale", "shift", "mean", "invstd")}
         self.bwd_ready = False
+        # > 0 while an autograd graph still needs this plan's activations for its backward
+        # (the reference's pipeline calls the UNet once per floor before one backward,
+        # models.py:190): such a plan is not reused by the next forward.
+        self.leases = 0
 
     def alloc_backward(self, eng: "UNetEngine"):
         if self.bwd_ready:
@@ -202,14 +206,25 @@ class UNetEngine:
             self.packed_ver.clear()
             self.flat_grad = None
 
+    MAX_LIVE_PLANS = 8        # forwards of one shape whose backward is still pending
+
     def plan(self, N, H, W) -> _Plan:
+        """A plan for this shape whose buffers nobody is waiting to run backward on."""
         key = (N, H, W)
-        p = self.plans.get(key)
-        if p is None:
-            if len(self.plans) >= 2:          # keep at most two shapes resident
-                self.plans.pop(next(iter(self.plans)))
-            p = _Plan(self, N, H, W)
-            self.plans[key] = p
+        pool = self.plans.get(key)
+        if pool is None:
+            for k in [k for k, v in self.plans.items() if all(q.leases == 0 for q in v)]:
+                if len(self.plans) >= 2:      # keep at most two idle shapes resident
+                    self.plans.pop(k)
+            pool = self.plans[key] = []
+        for p in pool:
+            if p.leases == 0:
+                return p
+        if len(pool) >= self.MAX_LIVE_PLANS:
+            raise L.FeaError(f"{len(pool)} forward passes of shape {key} are waiting for their backward; "
+                             "run backward (or drop the graphs / use torch.no_grad()) before calling the model again")
+        p = _Plan(self, N, H, W)
+        pool.append(p)
         return p
 
     def _ensure_flat_grad(self):
@@ -345,6 +360,7 @@ class UNetEngine:
             torch._foreach_add_([B[f"{b}.{i}.num_batches_tracked"] for b in BLOCKS for i in (1, 4)], 1)
         if taps is not None:
             self._export_taps(pl, taps)
+        pl.training = training
         self._last = (pl, training)
         return pl.logits
 
@@ -362,10 +378,11 @@ class UNetEngine:
                 taps[f"{blk}.3.act"] = pl.a3[blk].float().permute(0, 3, 1, 2).contiguous()
 
     # -------------------------------------------------------------- backward
-    def backward(self, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def backward(self, dlogits: torch.Tensor, plan: Optional[_Plan] = None) -> Dict[str, torch.Tensor]:
         """Gradients of every parameter for upstream gradient `dlogits`
-        ([N,classes,H,W] fp32).  Returns views into the flat gradient buffer."""
-        pl, training = self._last
+        ([N,classes,H,W] fp32).  Returns views into the flat gradient buffer.
+        `plan`: the plan of the forward this is the backward of (default: the last forward)."""
+        pl, training = self._last if plan is None else (plan, plan.training)
         if not training:
             raise L.FeaError("backward through eval-mode BatchNorm is not supported (the reference trains in train() mode)")
         pl.alloc_backward(self)

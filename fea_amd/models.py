@@ -37,6 +37,23 @@ def _resolve_dtype(compute_dtype) -> torch.dtype:
         raise ValueError(f"unsupported compute dtype {compute_dtype!r} (use 'fp32' or 'bf16')") from None
 
 
+class _Lease:
+    """Keeps a forward's plan (its saved activations) out of reuse until the backward has
+    run or the autograd graph holding it has been dropped."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        plan.leases += 1
+
+    def release(self):
+        if self.plan is not None:
+            self.plan.leases -= 1
+            self.plan = None
+
+    def __del__(self):
+        self.release()
+
+
 class _UNetFunction(torch.autograd.Function):
     """One autograd node for the whole UNet: forward enqueues the HIP forward,
     backward the HIP backward, and returns the parameter gradients in the
@@ -48,15 +65,20 @@ class _UNetFunction(torch.autograd.Function):
         logits = eng.forward(x, module.training)
         ctx.module = module
         ctx.names = module._param_names
+        ctx.plan = eng._last[0]
+        ctx.lease = _Lease(ctx.plan)
         # hand out a copy: the plan's logits buffer is overwritten by the next forward
         return logits.clone()
 
     @staticmethod
     def backward(ctx, dlogits):
         module = ctx.module
-        grads = module._engine().backward(dlogits)
-        out = tuple(grads[n] if p.requires_grad else None
+        grads = module._engine().backward(dlogits, plan=ctx.plan)
+        # copies: the flat gradient buffer is rewritten by the next backward (a second
+        # forward of the same graph, models.py:190), autograd accumulates what we return
+        out = tuple(grads[n].clone() if p.requires_grad else None
                     for n, p in zip(ctx.names, module.parameters()))
+        ctx.lease.release()
         return (None, None) + out
 
 

@@ -8,8 +8,11 @@ alone on the build-defined BCE+Dice loss.
 """
 from __future__ import annotations
 
+import json
 import math
-from typing import Optional
+import os
+import time
+from typing import Iterable, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -80,11 +83,15 @@ class GradBuckets:
 
 
 class UNetTrainer:
-    """config keys follow train_direct.py:166-185 where they apply:
-    learning_rate, weight_decay, num_epochs (cosine T_max), max_grad_norm."""
+    """config keys follow train_direct.py:166-185 where they apply: learning_rate,
+    weight_decay, batch_size, num_epochs (cosine T_max), checkpoint_dir, log_dir, save_every;
+    plus max_grad_norm (the reference hard-codes 1.0, train_direct.py:105).  Checkpoints
+    use the reference's dict schema (train_direct.py:127-135); scalars the reference sends
+    to TensorBoard go to `<log_dir>/metrics.jsonl`, one JSON object per step."""
 
     def __init__(self, model, config: Optional[dict] = None, distributed: bool = False, bucket_mb: float = 32.0):
-        cfg = dict(learning_rate=1e-4, weight_decay=1e-5, num_epochs=50, max_grad_norm=1.0)
+        cfg = dict(learning_rate=1e-4, weight_decay=1e-5, batch_size=4, num_epochs=50, max_grad_norm=1.0,
+                   checkpoint_dir="./checkpoints", log_dir="./logs", save_every=5)
         cfg.update(config or {})
         self.cfg = cfg
         self.model = model
@@ -129,3 +136,79 @@ class UNetTrainer:
 
     def epoch_end(self):
         self.sched.step()
+
+    # ---- epoch loop, checkpoints, metrics (train_direct.py:59-163) ----------------------
+    def _is_rank0(self) -> bool:
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+    def train_epoch(self, epoch: int, loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], log=None) -> float:
+        """One pass over `loader` (batches of (image [N,3,H,W] float, target [N,classes,H,W]
+        uint8), already on the device or not).  Returns the mean loss (train_direct.py:125).
+        The loss is read back once per epoch, not per step (no sync in the step loop)."""
+        dev = next(self.model.parameters()).device
+        losses = []
+        t0 = time.time()
+        n_img = 0
+        for batch_idx, (x, t) in enumerate(loader):
+            x = x.to(dev, non_blocking=True)
+            t = t.to(dev, non_blocking=True)
+            losses.append(self.step(x, t))
+            n_img += x.shape[0]
+        if not losses:
+            return float("nan")
+        vals = torch.stack([l.reshape(()) for l in losses]).cpu()        # one sync
+        dt = time.time() - t0
+        if log is not None and self._is_rank0():
+            for batch_idx, v in enumerate(vals.tolist()):
+                log.write(json.dumps({"epoch": epoch, "global_step": epoch * len(losses) + batch_idx,
+                                      "Loss/total": v}) + "\n")
+            log.write(json.dumps({"epoch": epoch, "Loss/epoch_mean": vals.mean().item(), "lr": self.sched.get_last_lr()[0],
+                                  "images_per_sec": n_img / dt if dt > 0 else None}) + "\n")
+            log.flush()
+        return vals.mean().item()
+
+    def save_checkpoint(self, epoch: int, filepath: str):
+        """Same dict schema as train_direct.py:127-135."""
+        torch.cuda.synchronize()
+        torch.save({
+            "epoch": epoch,
+            "model_state_dict": self.model.state_dict(),
+            "optimizer_state_dict": self.opt.state_dict(),
+            "scheduler_state_dict": self.sched.state_dict(),
+        }, filepath)
+
+    def load_checkpoint(self, filepath: str) -> int:
+        """Resume from a checkpoint written by save_checkpoint (or by the reference's
+        trainer for the model part: `module.` / `segmentation_model.` prefixes are accepted).
+        Returns the epoch stored in it."""
+        ckpt = torch.load(filepath, map_location="cpu", weights_only=True)
+        self.model.load_state_dict(ckpt["model_state_dict"], strict=False)
+        self.eng.invalidate()
+        try:
+            self.opt.load_state_dict(ckpt["optimizer_state_dict"])
+            self.sched.load_state_dict(ckpt["scheduler_state_dict"])
+        except (KeyError, ValueError):
+            pass            # a pipeline checkpoint of the reference: its optimizer covers other modules too
+        return int(ckpt.get("epoch", -1))
+
+    def train(self, make_loader, start_epoch: int = 0):
+        """The loop of DirectTrainer.train (train_direct.py:137-163).  `make_loader(epoch)`
+        returns the epoch's iterable of batches."""
+        cfg = self.cfg
+        rank0 = self._is_rank0()
+        log = None
+        if rank0:
+            os.makedirs(cfg["checkpoint_dir"], exist_ok=True)
+            os.makedirs(cfg["log_dir"], exist_ok=True)
+            log = open(os.path.join(cfg["log_dir"], "metrics.jsonl"), "a")
+        try:
+            for epoch in range(start_epoch, cfg["num_epochs"]):
+                self.train_epoch(epoch, make_loader(epoch), log)
+                self.sched.step()
+                if rank0 and (epoch + 1) % cfg["save_every"] == 0:
+                    self.save_checkpoint(epoch, os.path.join(cfg["checkpoint_dir"], f"checkpoint_epoch_{epoch}.pth"))
+            if rank0:
+                self.save_checkpoint(cfg["num_epochs"] - 1, os.path.join(cfg["checkpoint_dir"], "final_model.pth"))
+        finally:
+            if log is not None:
+                log.close()

@@ -14,7 +14,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-template <int SHAPE, int WAVES>
+// VAR 0: all fragments re-read every k-step (24 KB / wave-iteration)
+// VAR 1: half of the A fragments re-read per k-step (16 KB / wave-iteration: models reuse of
+//        halo rows across the three dy taps)
+// VAR 2: no LDS reads inside the loop (sustained MFMA rate at the clocks the device holds)
+template <int SHAPE, int WAVES, int VAR = 0>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void k(const u32x4* __restrict__ src, float* __restrict__ out, int iters) {
     constexpr int LDSB = 76 * 1024;
     __shared__ __attribute__((aligned(16))) char smem[LDSB];
@@ -54,14 +58,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void k(const u32x
         f32x4 acc[8][4];
         for (int m = 0; m < 8; ++m) for (int n = 0; n < 4; ++n) for (int e = 0; e < 4; ++e) acc[m][n][e] = 0.f;
         const int r = lane & 15, q = lane >> 4;
+        u32x4 a[8], b[4];
         for (int it = 0; it < iters; ++it) {
             const int tapoff = (it % 9) * 128;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int c = 4 * ks + q;
-                u32x4 a[8], b[4];
+                if (VAR != 2 || it == 0) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
+                    if (VAR == 1 && it > 0 && (m >> 2) != ks) continue;
                     const int row = (wave & 1) * 128 + m * 16 + r + (it % 9);
                     a[m] = *reinterpret_cast<const u32x4*>(smem + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
                 }
@@ -69,6 +75,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void k(const u32x
                 for (int n = 0; n < 4; ++n) {
                     const int row = 352 + n * 16 + r;
                     b[n] = *reinterpret_cast<const u32x4*>(smem + row * 128 + ((c ^ ((row >> 1) & 7)) << 4) + tapoff % 1024);
+                }
                 }
 #pragma unroll
                 for (int m = 0; m < 8; ++m)
@@ -82,16 +89,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void k(const u32x
     out[blockIdx.x * WAVES * 64 + tid] = res;
 }
 
-template <int SHAPE, int WAVES>
+template <int SHAPE, int WAVES, int VAR = 0>
 static void run(const u32x4* src, float* out, int iters, int blocks, const char* name) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<SHAPE, WAVES>), dim3(blocks), dim3(WAVES * 64), 0, 0, src, out, iters);
+    hipLaunchKernelGGL((k<SHAPE, WAVES, VAR>), dim3(blocks), dim3(WAVES * 64), 0, 0, src, out, iters);
     hipDeviceSynchronize();
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<SHAPE, WAVES>), dim3(blocks), dim3(WAVES * 64), 0, 0, src, out, iters);
+        hipLaunchKernelGGL((k<SHAPE, WAVES, VAR>), dim3(blocks), dim3(WAVES * 64), 0, 0, src, out, iters);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -118,5 +125,8 @@ int main(int argc, char** argv) {
     run<16, 4>(src, out, iters, 256, "16x16x32  4 waves, 1 block/CU");
     run<32, 8>(src, out, iters, 256, "32x32x16  8 waves, 1 block/CU");
     run<16, 8>(src, out, iters, 256, "16x16x32  8 waves, 1 block/CU");
+    run<16, 4, 1>(src, out, iters, 512, "16x16x32 4w 2blk/CU, A half re-read");
+    run<16, 4, 2>(src, out, iters, 512, "16x16x32 4w 2blk/CU, no LDS reads");
+    run<16, 4, 2>(src, out, iters, 256, "16x16x32 4w 1blk/CU, no LDS reads");
     return 0;
 }

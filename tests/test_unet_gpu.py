@@ -194,6 +194,95 @@ def test_module_contract_on_device():
     assert m.enc1[0].weight.grad.abs().sum() > 0
 
 
+def test_pipeline_call_site_two_floors_one_backward():
+    """the reference pipeline runs `[self.segmentation_model(fp) for fp in
+    floor_plan_images]` (models.py:190) and backpropagates through all of the outputs at
+    once.  Every forward must keep its own saved activations until its backward has run;
+    parameter gradients are the sum over floors, BN buffers see both updates."""
+    m, params, bufs = make(12, "fp32")
+    m.train()
+    g = torch.Generator().manual_seed(7)
+    floors = [torch.randn(2, 3, 32, 32, generator=g) for _ in range(3)]
+    dls = [torch.randn(2, 6, 32, 32, generator=g) / 2048 for _ in range(3)]
+    eng = m._engine()
+    taps = []
+    outs = []
+    m.zero_grad()
+    for fp in floors:                                   # the list comprehension of models.py:190
+        taps.append({})
+        eng.debug_taps = taps[-1]
+        outs.append(m(fp.cuda()))
+    eng.debug_taps = None
+    assert len({o.data_ptr() for o in outs}) == 3
+    torch.autograd.backward(outs, [d.cuda() for d in dls])
+    torch.cuda.synchronize()
+    want = None
+    b = bufs
+    for fp, dl, tp, out in zip(floors, dls, taps, outs):
+        forced = O.forced_from_taps({k: v.cpu() for k, v in tp.items()})
+        lo, go, b = O.grads_from_dlogits(params, b, fp, dl, forced=forced)
+        lo_free, _ = O.forward(params, bufs, fp, True)
+        assert rel_l2(out.detach(), lo_free) < 1e-4
+        want = go if want is None else {k: want[k] + go[k] for k in go}
+    for k, p in m.named_parameters():
+        if not cancelled(k):
+            assert rel_l2(p.grad, want[k]) < 1e-4, (k, rel_l2(p.grad, want[k]))
+    for k, buf in m.named_buffers():
+        if k.endswith("num_batches_tracked"):
+            assert int(buf) == 3
+        else:
+            assert rel_l2(buf, b[k]) < 1e-4, k
+    # all leases returned: the next forward reuses a resident plan
+    assert all(pl.leases == 0 for pool in eng.plans.values() for pl in pool)
+    n_plans = sum(len(v) for v in eng.plans.values())
+    m(floors[0].cuda()).sum().backward()
+    assert sum(len(v) for v in eng.plans.values()) == n_plans
+    # a graph dropped without backward gives its plan back too
+    y = m(floors[0].cuda())
+    del y
+    assert all(pl.leases == 0 for pool in eng.plans.values() for pl in pool)
+
+
+def test_trainer_loop_checkpoint_schema_and_resume(tmp_path):
+    """loop / config keys / checkpoint schema of DirectTrainer
+    (train_direct.py:127-163); resuming from a checkpoint continues bit-identically
+    (every kernel on the path is deterministic)."""
+    import json
+    cfg = dict(learning_rate=1e-3, weight_decay=1e-5, batch_size=2, num_epochs=2, save_every=1,
+               checkpoint_dir=str(tmp_path / "ck"), log_dir=str(tmp_path / "logs"))
+
+    def loader(epoch):
+        for i in range(2):
+            x, t = O.synthetic_batch(2, 32, 32, seed=100 + 10 * epoch + i)
+            yield x, t
+
+    torch.manual_seed(3)
+    ma = fea_amd.FloorPlanSegmentationModel(compute_dtype="bf16").cuda()
+    ta = UNetTrainer(ma, cfg)
+    ta.train(loader)
+    ck = torch.load(tmp_path / "ck" / "checkpoint_epoch_0.pth", map_location="cpu", weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict"} and ck["epoch"] == 0
+    assert list(ck["model_state_dict"]) == list(ma.state_dict())
+    final = torch.load(tmp_path / "ck" / "final_model.pth", map_location="cpu", weights_only=True)
+    assert final["epoch"] == 1
+    lines = [json.loads(l) for l in open(tmp_path / "logs" / "metrics.jsonl")]
+    assert sum("Loss/total" in l for l in lines) == 4 and sum("Loss/epoch_mean" in l for l in lines) == 2
+    # resume after epoch 0 in a fresh trainer: epoch 1 must land on the same weights
+    mb = fea_amd.FloorPlanSegmentationModel(compute_dtype="bf16").cuda()
+    tb = UNetTrainer(mb, dict(cfg, checkpoint_dir=str(tmp_path / "ck2"), log_dir=str(tmp_path / "logs2")))
+    assert tb.load_checkpoint(str(tmp_path / "ck" / "checkpoint_epoch_0.pth")) == 0
+    tb.train(loader, start_epoch=1)
+    for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert torch.equal(a, b), k
+    # the Inference entry point reads the same file
+    from fea_amd import Inference
+    inf = Inference(str(tmp_path / "ck" / "final_model.pth"), compute_dtype="bf16")
+    x, _ = O.synthetic_batch(1, 32, 32, seed=5)
+    ma.eval()
+    with torch.no_grad():
+        assert torch.equal(inf.predict([x])[0], ma(x.cuda()))
+
+
 def test_loss_autograd_and_iou():
     x = torch.randn(2, 6, 32, 32)
     t = (torch.rand(2, 6, 32, 32) < 0.2).to(torch.uint8)
