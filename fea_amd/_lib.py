@@ -62,6 +62,10 @@ SIGNATURES = {
     "fea_bce_dice_grad": (I, [P, P, P, P, P, F, I, I, L, P]),
     "fea_mask_iou": (I, [P, P, P, P, P, I, I, L, P]),
     "fea_binarise": (I, [P, P, L, P]),
+    "fea_resize_ksize": (I, [I, I]),
+    "fea_resize_coeffs": (I, [I, I, P, P]),
+    "fea_normalize_lut": (I, [P, P, I, P]),
+    "fea_resize_u8": (I, [P, I, I, I, P, P, I, I, P, P, I, P, P, I, I, P, I, P]),
 }
 
 _lib = None

@@ -207,6 +207,29 @@ int fea_mask_iou(const float* logits, const uint8_t* target, uint8_t* mask, long
 /* target = grey > 127 */
 int fea_binarise(const uint8_t* grey, uint8_t* out, long long n, void* stream);
 
+
+/* ---- input pipeline ------------------------------------------------
+ * The reference's per-image transform, custom_dataset.py:23-28 (applied at :69-71):
+ * Resize((S,S)) on a PIL image -> ToTensor() -> Normalize(mean, std).  The resize is
+ * Pillow's antialiased bilinear resample (the library torchvision forwards PIL images to),
+ * reproduced bit for bit in fixed point. */
+/* HOST helpers (no GPU work): taps per output sample; tables bounds[2*out] = (first input
+ * sample, count) and coeffs[out*ksize] (22-bit fixed point) as Pillow computes them.
+ * fea_resize_coeffs returns ksize (>0) or a negative error. */
+int fea_resize_ksize(int in_size, int out_size);
+int fea_resize_coeffs(int in_size, int out_size, int* bounds, int* coeffs);
+/* HOST helper: lut[c*256+v] = ((float)v / 255 - mean[c]) / std[c] in float32, the exact
+ * value ToTensor + Normalize give for byte v of channel c. */
+int fea_normalize_lut(const float* mean, const float* stdv, int C, float* lut);
+/* src u8 [src_h][src_w][C] (C = 1 or 3, device) -> tmp u8 [src_h][W][C] -> dst:
+ *   epilogue 0: u8  [H][W][C]  resized image
+ *   epilogue 1: f32 [C][H][W]  lut[c][v]         (device lut of fea_normalize_lut: the module's input)
+ *   epilogue 2: u8  [C][H][W]  v > threshold     (mask target, threshold 127)
+ * x/y tables: DEVICE copies of fea_resize_coeffs(src_w, W) / (src_h, H). */
+int fea_resize_u8(const uint8_t* src, int src_h, int src_w, int C, uint8_t* tmp, void* dst, int H, int W,
+                  const int* xbounds, const int* xcoef, int xks, const int* ybounds, const int* ycoef, int yks,
+                  int epilogue, const float* lut, int threshold, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
