@@ -35,6 +35,8 @@ SIGNATURES = {
     "fea_conv3x3_first_wgrad": (I, [P, I, P, P, P, Z, I, I, I, I, I, I, P]),
     "fea_conv3x3": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
     "fea_conv3x3_dgrad_bnred": (I, [P, I, P, P, I, P, I, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "fea_conv3x3_bias_relu": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, I, P]),
+    "fea_conv3x3_first_bias_relu": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "fea_conv1x1": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
     "fea_conv_num_tiles": (I, [I, I, I]),
     "fea_upconv2x2_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),

@@ -20,6 +20,8 @@
 //   EPI 0   y[pixel][cout0+col] (+bias, + BatchNorm partial sums)
 //   EPI 1   pixel-shuffle store of ConvTranspose2d forward: GEMM column
 //           n = ab*Cup + co goes to pixel (2i+a, 2j+b), channel co.
+//   EPI 3   inference with BatchNorm folded into the weights: relu(acc + bias), stored as the
+//           activated tensor (channel slice `ldy`), plus its 2x2 max-pool when `pool` is set
 //   EPI 2   EPI 0 + the first pass of the NEXT BatchNorm backward fused into the
 //           store loop: the tile just computed is an activation gradient da; with the
 //           layer's pre-BN output y, (sum g, sum g*xhat) per channel are written per
@@ -43,6 +45,8 @@ struct IgemmArgs {
     const void* ybn; int ldybn;
     const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
     float* red_part;   // [pixel tile][Cout][2]
+    // EPI 3: optional 2x2 max-pool of the activated output, [N][H/2][W/2] pixels, ldpool apart
+    void* pool; int ldpool;
 };
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc16[m][n][j] += bv[n];
+                for (int j = 0; j < 4; ++j) acc16[m][n][j] = EPI == 3 ? fmaxf(acc16[m][n][j] + bv[n], 0.f) : acc16[m][n][j] + bv[n];
 
         if (EPI == 0 && g.stats) {
 #pragma unroll
@@ -661,6 +665,33 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
                 if (ok) {
                     const u32x4 v = *reinterpret_cast<const u32x4*>(smem + p * EPI_STRIDE + c * 16);
                     *reinterpret_cast<u32x4*>(yg + (long long)pix * g.ldy + c_off + c * 8) = v;
+                }
+            }
+            if constexpr (EPI == 3) {
+                if (g.pool) {
+                    // 2x2 max-pool of the staged tile (tile origins are even, H and W are even:
+                    // every window lies inside one tile and is either whole or outside the image)
+                    constexpr int TWP = TW / 2;
+                    T* __restrict__ pg = (T*)g.pool + (long long)n_img * (H / 2) * (W / 2) * g.ldpool + cout0;
+#pragma unroll
+                    for (int i = 0; i < (CPR + 3) / 4; ++i) {
+                        const int q = i * 256 + tid;
+                        const int pp = q / CPR, c = q - pp * CPR;
+                        const int py = pp / TWP, px = pp - py * TWP;
+                        if (pp < 64 && y0 + 2 * py < H && x0 + 2 * px < W) {
+                            const int p00 = (2 * py) * TW + 2 * px;
+                            bf16x8 v[4];
+                            v[0] = *reinterpret_cast<const bf16x8*>(smem + p00 * EPI_STRIDE + c * 16);
+                            v[1] = *reinterpret_cast<const bf16x8*>(smem + (p00 + 1) * EPI_STRIDE + c * 16);
+                            v[2] = *reinterpret_cast<const bf16x8*>(smem + (p00 + TW) * EPI_STRIDE + c * 16);
+                            v[3] = *reinterpret_cast<const bf16x8*>(smem + (p00 + TW + 1) * EPI_STRIDE + c * 16);
+                            bf16x8 o;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                o[j] = (__bf16)fmaxf(fmaxf((float)v[0][j], (float)v[1][j]), fmaxf((float)v[2][j], (float)v[3][j]));
+                            *reinterpret_cast<bf16x8*>(pg + ((long long)(y0 / 2 + py) * (W / 2) + x0 / 2 + px) * g.ldpool + c * 8) = o;
+                        }
+                    }
                 }
             }
         }
@@ -827,6 +858,42 @@ extern "C" int fea_conv3x3_first(const float* x, const void* w_packed, const flo
     a.ldx = 0; a.ldy = ldy; a.H = H; a.W = W; a.Cin = C; a.Cout = Cout; a.Cup = Cout;
     a.x_img_stride = (long long)C * H * W; a.y_img_stride = (long long)H * W * ldy;
     return launch_igemm<__bf16, 3, 0>(a, N, (hipStream_t)stream);
+}
+
+// Inference with BatchNorm folded into weights and bias (eval mode, models.py:28-33 collapse to
+// conv + bias + ReLU); optional MaxPool2d(2) output (models.py:24,38-41).
+extern "C" int fea_conv3x3_bias_relu(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
+                                     void* pool, int ldpool, int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    const char* who = "fea_conv3x3_bias_relu";
+    int rc = check_common(who, x, ldx, w, y, ldy, N, H, W, Cin, Cout, dtype);
+    if (rc) return rc;
+    FEA_CHECK(dtype == FEA_BF16, FEA_E_UNSUPPORTED_SHAPE, "%s: bf16 only (fp32: fea_conv3x3 + fea_bn_eval_coeffs + fea_bn_relu_pool)", who);
+    FEA_CHECK(ldy >= Cout && bias, FEA_E_BADARG, "%s: ldy=%d < Cout=%d or no bias", who, ldy, Cout);
+    FEA_CHECK(!pool || (H % 2 == 0 && W % 2 == 0 && ldpool >= Cout && ldpool % 8 == 0 && (uintptr_t)pool % 16 == 0), FEA_E_BADARG,
+              "%s: pooled output needs even H, W and an aligned buffer", who);
+    IgemmArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = nullptr;
+    a.ldx = ldx; a.ldy = ldy; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cup = Cout;
+    a.x_img_stride = (long long)H * W * ldx; a.y_img_stride = (long long)H * W * ldy;
+    a.pool = pool; a.ldpool = ldpool;
+    return launch_igemm<__bf16, 0, 3>(a, N, (hipStream_t)stream);
+}
+
+extern "C" int fea_conv3x3_first_bias_relu(const float* x, const void* w_packed, const float* bias, void* y, int ldy,
+                                           int N, int C, int H, int W, int Cout, int dtype, void* stream) {
+    const char* who = "fea_conv3x3_first_bias_relu";
+    FEA_CHECK(dtype == FEA_BF16, FEA_E_UNSUPPORTED_SHAPE, "%s: bf16 only", who);
+    FEA_CHECK(x && w_packed && y && bias, FEA_E_BADARG, "%s: null pointer", who);
+    FEA_CHECK(N > 0 && H > 0 && W > 0, FEA_E_BADARG, "%s: bad dims", who);
+    FEA_CHECK(C > 0 && 9 * C <= 64, FEA_E_UNSUPPORTED_SHAPE, "%s: C=%d (9*C must be <= 64)", who, C);
+    FEA_CHECK(Cout > 0 && Cout % 64 == 0 && ldy >= Cout && ldy % 8 == 0, FEA_E_UNSUPPORTED_SHAPE, "%s: Cout=%d ldy=%d", who, Cout, ldy);
+    FEA_CHECK(((uintptr_t)y % 16 == 0) && ((uintptr_t)w_packed % 16 == 0) && ((uintptr_t)x % 4 == 0), FEA_E_BADARG, "%s: alignment", who);
+    FEA_CHECK((long long)H * W * ldy < (1ll << 31) && (long long)C * H * W < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "%s: image too large", who);
+    IgemmArgs a{};
+    a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.stats = nullptr;
+    a.ldx = 0; a.ldy = ldy; a.H = H; a.W = W; a.Cin = C; a.Cout = Cout; a.Cup = Cout;
+    a.x_img_stride = (long long)C * H * W; a.y_img_stride = (long long)H * W * ldy;
+    return launch_igemm<__bf16, 3, 3>(a, N, (hipStream_t)stream);
 }
 
 extern "C" int fea_conv1x1(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, float* stats,

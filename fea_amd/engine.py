@@ -167,6 +167,9 @@ class UNetEngine:
         self.plans: Dict[tuple, _Plan] = {}
         self.packed: Dict[str, torch.Tensor] = {}
         self.packed_ver: Dict[str, int] = {}
+        # eval mode, bf16: BatchNorm folded into packed weights + bias (name -> (version, w, bias))
+        self.fold_bn = os.environ.get("FEA_AMD_FOLD_BN", "1") != "0"
+        self.folded: Dict[str, tuple] = {}
         self.flat_grad: Optional[torch.Tensor] = None
         self.grad_views: Dict[str, torch.Tensor] = {}
         self.grad_offsets: Dict[str, tuple] = {}
@@ -204,6 +207,7 @@ class UNetEngine:
             self.plans.clear()
             self.packed.clear()
             self.packed_ver.clear()
+            self.folded.clear()
             self.flat_grad = None
 
     MAX_LIVE_PLANS = 8        # forwards of one shape whose backward is still pending
@@ -268,6 +272,34 @@ class UNetEngine:
         co, ci = p.shape[0], p.shape[1]
         return self._pack(name + "/f", p, p.numel(), "fea_pack_conv3x3", co, ci, 0)
 
+    def _w_folded(self, name: str):
+        """Packed weights and bias of conv `name` with its eval-mode BatchNorm folded in:
+        w' = w * gamma / sqrt(running_var + eps), b' = (b - running_mean) * that + beta
+        (models.py:28-29 / 31-32 in eval mode).  Re-made when any of the six tensors changes."""
+        blk, idx = name.rsplit(".", 1)
+        bn = f"{blk}.{int(idx) + 1}"
+        P, B = self._params(), self._bufs()
+        deps = [P[name + ".weight"], P[name + ".bias"], P[bn + ".weight"], P[bn + ".bias"],
+                B[bn + ".running_mean"], B[bn + ".running_var"]]
+        ver = (self._gen, tuple(t._version for t in deps), tuple(t.data_ptr() for t in deps))
+        ent = self.folded.get(name)
+        if ent is None or ent[0] != ver:
+            with torch.no_grad():
+                scale = deps[2] * torch.rsqrt(deps[5] + BN_EPS)
+                wf = (deps[0] * scale.view(-1, 1, 1, 1)).contiguous()
+                bf = ((deps[1] - deps[4]) * scale + deps[3]).contiguous()
+            co, ci = wf.shape[0], wf.shape[1]
+            if name == "enc1.0":
+                ks = (9 * self.in_channels + 31) // 32
+                numel, fn, args = ks * 64 * 32, "fea_pack_conv3x3_first", (64, self.in_channels)
+            else:
+                numel, fn, args = wf.numel(), "fea_pack_conv3x3", (co, ci, 0)
+            buf = ent[1] if ent is not None else torch.empty(numel, dtype=self.dtype, device=self.device)
+            L.call(fn, wf, buf, *args, self.code, L.stream_ptr())
+            ent = (ver, buf, bf)
+            self.folded[name] = ent
+        return ent[1], ent[2]
+
     def _w_dgrad(self, name: str):
         p = self._params()[name + ".weight"]
         co, ci = p.shape[0], p.shape[1]
@@ -299,11 +331,21 @@ class UNetEngine:
         taps = self.debug_taps
 
         pl.x_in = x
+        fold = (not training) and self.fold_bn and self.dtype == torch.bfloat16 and taps is None
         if not self.first_direct:
             L.call("fea_im2col3x3_nchw", x, pl.xcol, N, self.in_channels, H, W, self.kpad, code, S)
 
         def conv_bn(name, inp, ld_in, cin, h, w, cout, out_full, ld_full, out_pool):
             """conv -> BN statistics -> scale/shift -> ReLU(+pool)"""
+            if fold and (name != "enc1.0" or self.first_direct):
+                # eval mode: one kernel, relu(conv(x, w') + b') (+ pooled copy)
+                wp, bf = self._w_folded(name)
+                if name == "enc1.0":
+                    L.call("fea_conv3x3_first_bias_relu", pl.x_in, wp, bf, out_full, ld_full, N, self.in_channels, h, w, cout, code, S)
+                else:
+                    L.call("fea_conv3x3_bias_relu", inp, ld_in, wp, bf, out_full, ld_full, out_pool, cout if out_pool is not None else 0,
+                           N, h, w, cin, cout, code, S)
+                return
             y = pl.y[name]
             stats = pl.stats if training else None
             wp = self._w_fwd(name)

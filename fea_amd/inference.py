@@ -66,9 +66,11 @@ def reduce_counts(inter: torch.Tensor, union: torch.Tensor, group=None):
 
 
 class TiledSegmenter:
-    """Batched, tiled eval-mode inference + mask / IoU for large images."""
+    """Batched, tiled eval-mode inference + mask / IoU for large images.  A window computes
+    (core + 2*halo)^2 pixels for core^2 useful ones: core 1024 (1.41x) runs 2048x2048 images
+    45 % faster than core 512 (1.89x) on one MI355X (scripts/bench_infer.py)."""
 
-    def __init__(self, model: FloorPlanSegmentationModel, core: int = 512, halo: int = HALO, window_batch: int = 16):
+    def __init__(self, model: FloorPlanSegmentationModel, core: int = 1024, halo: int = HALO, window_batch: int = 4):
         self.model = model.eval()
         self.core, self.halo, self.window_batch = core, halo, window_batch
 

@@ -109,6 +109,17 @@ int fea_conv3x3_dgrad_bnred(const void* dy, int lddy, const void* w_packed, void
                             const void* y, int ldy_bn, const float* scale, const float* shift,
                             const float* save_mean, const float* save_invstd, float* part,
                             int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* Eval-mode inference with BatchNorm folded into the packed weights and the bias
+ * (w' = w * gamma/sqrt(var+eps) per output channel, b' = (b - mean) * that + beta):
+ * Conv2d -> BatchNorm2d(eval) -> ReLU of models.py:28-33 in one kernel,
+ * y = relu(conv3x3(x, w') + b') written as the activated tensor (channel slice `ldy`);
+ * when `pool` is given (H, W even) also MaxPool2d(2) of it (models.py:24,38-41),
+ * [N][H/2][W/2] pixels `ldpool` elements apart.  bf16 only. */
+int fea_conv3x3_bias_relu(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
+                          void* pool, int ldpool, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* The same for the first layer (x fp32 NCHW, weights from fea_pack_conv3x3_first). */
+int fea_conv3x3_first_bias_relu(const float* x, const void* w_packed, const float* bias, void* y, int ldy,
+                                int N, int C, int H, int W, int Cout, int dtype, void* stream);
 /* 1x1 GEMM over pixel rows (enc1.0 on im2col rows); same epilogue as above. */
 int fea_conv1x1(const void* x, int ldx, const void* w_packed, const float* bias, void* y, int ldy,
                 float* stats, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);

@@ -159,6 +159,37 @@ def test_conv3x3_wgrad(dt, shape):
     check(dW, ref, dt, "conv3x3 wgrad", scale=0.5 if dt == torch.bfloat16 else 1.0)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64), (1, 16, 16, 128, 128), (1, 24, 40, 64, 128), (1, 8, 8, 192, 64),
+                                   (3, 16, 64, 64, 192), (1, 2, 2, 128, 256)])
+@pytest.mark.parametrize("pooled", [False, True])
+def test_conv3x3_bias_relu_pool_inference_kernel(shape, pooled):
+    """Folded-BatchNorm inference kernel: relu(conv3x3 + bias) (+ MaxPool2d(2)) against
+    F.conv2d / F.relu / F.max_pool2d on bf16-rounded inputs.  The pooled output must be exactly
+    the max over the stored (bf16) activations."""
+    dt = torch.bfloat16
+    code = L.dt_code(dt)
+    n, h, w, ci, co = shape
+    g = torch.Generator().manual_seed(21)
+    x = rnd(dt, n, ci, h, w, gen=g)
+    wt = (rnd(dt, co, ci, 3, 3, gen=g) / (3 * ci ** 0.5)).to(dt).float()
+    bias = torch.randn(co, generator=g) * 0.3
+    ref = F.relu(F.conv2d(x, wt, bias, padding=1))
+    wp = torch.empty(9 * co * ci, dtype=dt, device=DEV)
+    L.call("fea_pack_conv3x3", wt.to(DEV), wp, co, ci, 0, code, S())
+    ldy, off = co + 64, 64
+    y = torch.full((n, h, w, ldy), float("nan"), dtype=dt, device=DEV)
+    pool = torch.full((n, h // 2, w // 2, co + 8), float("nan"), dtype=dt, device=DEV) if pooled else None
+    L.call("fea_conv3x3_bias_relu", to_nhwc(x, dt), ci, wp, bias.to(DEV), view_ptr(y, off), ldy,
+           view_ptr(pool, 8) if pooled else None, co + 8 if pooled else 0, n, h, w, ci, co, code, S())
+    torch.cuda.synchronize()
+    got = from_nhwc(y, co, off)
+    check(got, ref, dt, "conv+bias+relu")
+    assert (got >= 0).all() and torch.isnan(y[..., :off].float()).all()
+    if pooled:
+        assert torch.equal(from_nhwc(pool, co, 8), F.max_pool2d(got, 2)), "pooled output != max of the stored activations"
+        assert torch.isnan(pool[..., :8].float()).all()
+
+
 @pytest.mark.parametrize("cin", [3, 1, 5, 7])
 @pytest.mark.parametrize("hw", [(32, 48), (16, 16), (40, 72)])
 def test_first_layer_direct_path(cin, hw):
@@ -183,6 +214,10 @@ def test_first_layer_direct_path(cin, hw):
     torch.cuda.synchronize()
     check(from_nhwc(y, co, 64), ref, dt, "first-layer conv")
     assert torch.isnan(y[..., :64].float()).all(), "wrote outside its channel slice"
+    y2 = torch.full((n, h, w, co), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_conv3x3_first_bias_relu", xd, wp, bias.to(DEV), y2, co, n, cin, h, w, co, code, S())
+    torch.cuda.synchronize()
+    check(from_nhwc(y2, co), F.relu(ref), dt, "first-layer conv + bias + relu (inference)")
     s = stats.double().sum(0).cpu()
     ref_s = torch.stack([ref.double().sum((0, 2, 3)), (ref.double() ** 2).sum((0, 2, 3))], 1)
     assert rel_l2(s, ref_s) < 1e-5, "BN partial sums"

@@ -283,6 +283,41 @@ def test_trainer_loop_checkpoint_schema_and_resume(tmp_path):
         assert torch.equal(inf.predict([x])[0], ma(x.cuda()))
 
 
+def test_eval_with_folded_batchnorm_matches_unfolded_and_oracle():
+    """in eval mode (bf16) BatchNorm is folded into the packed weights and the
+    conv kernel applies bias + ReLU (+ pool) itself.  Same logits as the unfolded path within
+    bf16 rounding, tracks the oracle, and follows in-place changes of the running statistics."""
+    torch.manual_seed(8)
+    m = fea_amd.FloorPlanSegmentationModel(compute_dtype="bf16").cuda()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.uniform_(-0.2, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.2, 0.2)
+    m.eval()
+    eng = m._engine()
+    x, _ = O.synthetic_batch(2, 64, 48, seed=3)
+    params, bufs = O.split_state({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    want, _ = O.forward(params, bufs, x, False)
+    with torch.no_grad():
+        assert eng.fold_bn
+        folded = m(x.cuda()).cpu()
+        eng.fold_bn = False
+        plain = m(x.cuda()).cpu()
+        eng.fold_bn = True
+        assert rel_l2(folded, plain) < 2e-2 and rel_l2(folded, want) < 3e-2 and rel_l2(plain, want) < 3e-2
+        # running statistics changed in place (e.g. load_state_dict while in eval mode)
+        m.enc2[1].running_mean.add_(0.5)
+        m.dec1[4].running_var.mul_(3.0)
+        folded2 = m(x.cuda()).cpu()
+        eng.fold_bn = False
+        plain2 = m(x.cuda()).cpu()
+        eng.fold_bn = True
+        assert rel_l2(folded2, plain2) < 2e-2 and rel_l2(folded2, folded) > 5e-2
+
+
 def test_loss_autograd_and_iou():
     x = torch.randn(2, 6, 32, 32)
     t = (torch.rand(2, 6, 32, 32) < 0.2).to(torch.uint8)
