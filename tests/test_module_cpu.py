@@ -76,3 +76,13 @@ def test_flat_gradient_layout_is_reverse_forward_and_complete():
         prev_end = off + numel
         assert eng.grad_views[n].shape == dict(m.named_parameters())[n].shape
     assert eng.flat_grad.numel() >= 31_043_846
+
+
+def test_product_synthetic_batch_is_the_oracles():
+    """bench.py / smoke() take their inputs from fea_amd.data.synthetic_batch; the CPU baseline
+    takes the oracle's: they must be the same tensors."""
+    from fea_amd.data import synthetic_batch
+    from oracle import unet_oracle as O
+    a, ta = synthetic_batch(2, 48, 32, seed=77)
+    b, tb = O.synthetic_batch(2, 48, 32, seed=77)
+    assert torch.equal(a, b) and torch.equal(ta, tb)
