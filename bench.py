@@ -81,7 +81,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # FEA_BENCH_FORCE_DIST=1: take the RCCL / bucketed all-reduce path even with one rank (rehearsal)
+    distributed = world > 1 or (os.environ.get("FEA_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     torch.cuda.set_device(local)
     if distributed:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
