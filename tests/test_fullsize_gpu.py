@@ -1,0 +1,91 @@
+"""Size-independent properties at BASELINE.json's full size (configs[2]: batch 64, 512x512,
+bf16), where the CPU oracle would take minutes per pass:
+
+  * determinism: the same step twice gives bit-identical logits, loss and gradients (every
+    reduction on the path has a fixed order);
+  * the second-stream weight-gradient schedule gives bit-identical gradients to the
+    single-stream one (no race between the dY ring, the wgrad stream and the main stream);
+  * linearity of backward in the upstream gradient: backward(2*dl) == 2*backward(dl) exactly
+    (scaling by a power of two commutes with every rounding on the path);
+  * eval-mode batch independence: logits of the 64-batch == logits of its two halves;
+  * BatchNorm: the batch statistics the conv epilogue accumulated reproduce mean / var of
+    the stored pre-BN tensor.
+"""
+import pytest
+import torch
+
+import fea_amd
+from fea_amd import functional as Fn
+from fea_amd.data import synthetic_batch
+
+pytestmark = pytest.mark.gpu
+N, S = 64, 512
+
+
+@pytest.fixture(scope="module")
+def setup():
+    torch.manual_seed(0)
+    m = fea_amd.FloorPlanSegmentationModel(compute_dtype="bf16").cuda().train()
+    x, t = synthetic_batch(N, S, S, seed=99)
+    x = (x + 0.05 * torch.randn(x.shape, generator=torch.Generator().manual_seed(2))).cuda()
+    return m, x, t.cuda()
+
+
+def _fwd_bwd(m, x, t, scale=1.0, overlap=True):
+    eng = m._engine()
+    eng.overlap_wgrad = overlap
+    state = {k: v.clone() for k, v in m.state_dict().items()}     # forward updates the BN buffers
+    logits = eng.forward(x, True).clone()
+    loss, dl = Fn.bce_dice_loss_and_grad(logits, t)
+    eng.backward(dl * scale)
+    torch.cuda.synchronize()
+    grads = eng.flat_grad.clone()
+    m.load_state_dict(state)
+    eng.overlap_wgrad = True
+    return logits, loss.clone(), grads
+
+
+def test_step_is_deterministic_and_stream_schedule_does_not_matter(setup):
+    m, x, t = setup
+    l1, loss1, g1 = _fwd_bwd(m, x, t)
+    l2, loss2, g2 = _fwd_bwd(m, x, t)
+    assert torch.isfinite(loss1).all() and torch.isfinite(g1).all() and g1.abs().sum() > 0
+    assert torch.equal(l1, l2) and torch.equal(loss1, loss2) and torch.equal(g1, g2)
+    _, _, g3 = _fwd_bwd(m, x, t, overlap=False)
+    assert torch.equal(g1, g3)
+
+
+def test_backward_is_linear_in_the_upstream_gradient(setup):
+    m, x, t = setup
+    _, _, g1 = _fwd_bwd(m, x, t)
+    _, _, g2 = _fwd_bwd(m, x, t, scale=2.0)
+    assert torch.equal(g2, 2 * g1)
+
+
+def test_eval_logits_do_not_depend_on_the_batch_they_are_computed_in(setup):
+    m, x, _ = setup
+    m.eval()
+    try:
+        with torch.no_grad():
+            full = m(x)
+            a, b = m(x[:32].contiguous()), m(x[32:].contiguous())
+        assert torch.equal(full, torch.cat([a, b]))
+    finally:
+        m.train()
+
+
+def test_batch_statistics_match_the_stored_pre_bn_tensor(setup):
+    m, x, _ = setup
+    eng = m._engine()
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    eng.forward(x, True)
+    pl = eng._last[0]
+    for name in ("enc1.0", "enc2.3", "bottleneck.0", "dec1.3"):
+        y = pl.y[name].float()
+        mean = y.mean((0, 1, 2))
+        var = y.var((0, 1, 2), unbiased=False)
+        cf = pl.coef[name]
+        # the kernel sums the fp32 accumulators, the stored tensor is their bf16 rounding
+        assert torch.allclose(cf["mean"], mean, rtol=2e-3, atol=2e-3 * float(var.sqrt().mean())), name
+        assert torch.allclose(cf["invstd"], torch.rsqrt(var + 1e-5), rtol=5e-3), name
+    m.load_state_dict(state)
