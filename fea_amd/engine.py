@@ -510,17 +510,27 @@ class UNetEngine:
             c = CH[blk]
             n3, n0 = f"{blk}.3", f"{blk}.0"
             bn_bwd(n3, da_full, ld_da, dpool, h, w, c)
-            wgrad("fea_conv3x3_wgrad", (ring["dY"], c, pl.a0[blk], c, g[n3 + ".weight"], pl.ws, pl.ws_bytes, N, h, w, c, c, code),
-                  (n3 + ".weight", n3 + ".bias", f"{blk}.4.weight", f"{blk}.4.bias"))
+            dy3 = ring["dY"]
+
+            def wg3():
+                # after the dgrad that shares its input: the weight gradient then runs beside
+                # the HBM-bound BatchNorm backward of X.0 instead of beside an MFMA-bound dgrad
+                wgrad("fea_conv3x3_wgrad", (dy3, c, pl.a0[blk], c, g[n3 + ".weight"], pl.ws, pl.ws_bytes, N, h, w, c, c, code),
+                      (n3 + ".weight", n3 + ".bias", f"{blk}.4.weight", f"{blk}.4.bias"))
+
             if fuse:
                 cf0 = pl.coef[n0]
                 L.call("fea_conv3x3_dgrad_bnred", ring["dY"], c, self._w_dgrad(n3), pl.gmid, c, pl.y[n0], c,
                        cf0["scale"], cf0["shift"], cf0["mean"], cf0["invstd"], pl.part, N, h, w, c, c, code, S)
+                wg3()
                 bn_bwd(n0, pl.gmid, c, None, h, w, c, reduced_tiles=L.call("fea_conv_num_tiles", N, h, w))
             else:
                 L.call("fea_conv3x3", ring["dY"], c, self._w_dgrad(n3), None, pl.gmid, c, None, N, h, w, c, c, code, S)
+                wg3()
                 bn_bwd(n0, pl.gmid, c, None, h, w, c)
             names0 = (n0 + ".weight", n0 + ".bias", f"{blk}.1.weight", f"{blk}.1.bias")
+            if d_in is not None:             # dgrad first, see wg3()
+                L.call("fea_conv3x3", ring["dY"], c, self._w_dgrad(n0), None, d_in, ld_din, din_stats, N, h, w, c, cin, code, S)
             if blk == "enc1" and self.first_direct:
                 wgrad("fea_conv3x3_first_wgrad", (ring["dY"], c, pl.x_in, g[n0 + ".weight"], pl.ws, pl.ws_bytes,
                                                   N, self.in_channels, h, w, c, code), names0)
@@ -529,8 +539,6 @@ class UNetEngine:
                                                    N, h, w, self.kpad, self.in_channels, c, code), names0)
             else:
                 wgrad("fea_conv3x3_wgrad", (ring["dY"], c, inp, ld_in, g[n0 + ".weight"], pl.ws, pl.ws_bytes, N, h, w, cin, c, code), names0)
-            if d_in is not None:
-                L.call("fea_conv3x3", ring["dY"], c, self._w_dgrad(n0), None, d_in, ld_din, din_stats, N, h, w, c, cin, code, S)
 
         # head
         nblk = L.call("fea_head_bwd_blocks", N, H, W)
