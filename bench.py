@@ -26,6 +26,10 @@ PEAK_F32_TFLOPS = 157.3         # f32-input MFMA
 GFLOP_TRAIN_512 = 1156.5        # per image, fwd + dgrad + wgrad
 
 
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes over one training step (profiles/r1_pmc_hbm_traffic.txt)
+PMC_TRAFFIC_DOMINANT = 1.911e9
+
+
 def train_gflop_per_image(h, w):
     return GFLOP_TRAIN_512 * (h * w) / (512.0 * 512.0)
 
@@ -128,6 +132,7 @@ def main():
         prof, L.PROFILE = L.PROFILE, None
         per = {}
         dom = [0.0, 0, 0.0]                     # dominant kernel: ms, launches, flops
+        dom_bytes = [0.0]                       # its algorithmic HBM bytes (activations in + out, weights once)
         for name, e0, e1, args in prof:
             ms = e0.elapsed_time(e1)
             d = per.setdefault(name, [0.0, 0, 0.0])
@@ -140,6 +145,8 @@ def main():
                 # igemm_kernel<bf16, MODE 0, BN 128, EPI 0, TWS 5>: Cout % 128 == 0 and W >= 32
                 if cout % 128 == 0 and wdt >= 32:
                     dom[0] += ms; dom[1] += 1; dom[2] += fl
+                    n_, h_, w_, ci_, co_ = args[7:12]
+                    dom_bytes[0] += 2.0 * n_ * h_ * w_ * (ci_ + co_) + 2.0 * 9 * ci_ * co_
             elif name == "fea_conv3x3_dgrad_bnred":
                 n, h, w, cin, cout = args[12:17]
                 fl = 2.0 * n * h * w * cin * cout * 9
@@ -152,7 +159,11 @@ def main():
         roof = {"bound": "mfma",
                 "kernel": "igemm_kernel<bf16, MODE 0 (3x3), 128 columns, EPI 0, 8x32 tile> = fea_conv3x3 launches with Cout % 128 == 0 "
                           "(forward and data-gradient convolutions)",
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                # HBM bytes per launch from the PMC passes (profiles/r1_pmc_hbm_traffic.txt: (2*FETCH_SIZE + WRITE_SIZE)
+                # * 1024, averaged over this kernel's launches of one step); measured on the default workload only
+                "traffic": PMC_TRAFFIC_DOMINANT if (a.batch == 64 and a.size == 512 and a.dtype == "bf16") else None,
+                "traffic_unit": "bytes per launch (HBM, PMC)", "algorithmic_bytes_per_launch": dom_bytes[0] / dom[1],
                 "avg_launch_ms": dom[0] / dom[1], "launches_per_step": dom[1] // NREP,
                 "algorithmic_flop_per_launch": "2*N*H*W*Cin*Cout*9 (summed over the launches)",
                 "mfma_kernels_tflops": {k: v[2] / (v[0] * 1e-3) / 1e12 for k, v in per.items() if v[2] > 0},

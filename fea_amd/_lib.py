@@ -41,6 +41,7 @@ SIGNATURES = {
     "fea_conv_num_tiles": (I, [I, I, I]),
     "fea_upconv2x2_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "fea_upconv2x2_bwd_data": (I, [P, I, P, P, I, I, I, I, I, I, I, P]),
+    "fea_upconv2x2_bwd_data_bnred": (I, [P, I, P, P, I, P, I, P, P, P, P, P, I, I, I, I, I, I, P]),
     "fea_wgrad_ws_bytes": (Z, [I, I, I, I, I, I, I]),
     "fea_conv3x3_wgrad": (I, [P, I, P, I, P, P, Z, I, I, I, I, I, I, P]),
     "fea_conv1x1_im2col_wgrad": (I, [P, I, P, I, P, P, Z, I, I, I, I, I, I, I, P]),

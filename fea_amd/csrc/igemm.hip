@@ -844,6 +844,28 @@ extern "C" int fea_conv3x3_dgrad_bnred(const void* dy, int lddy, const void* w_p
     return launch_igemm<__bf16, 0, 2>(a, N, (hipStream_t)stream);
 }
 
+// ConvTranspose2d data gradient fused with the reduction of the BatchNorm backward that
+// consumes it (the layer in front of the transposed conv is conv -> BN -> ReLU, models.py:31-33).
+extern "C" int fea_upconv2x2_bwd_data_bnred(const void* dy, int lddy, const void* w, void* dx, int lddx,
+                                            const void* y, int ldy_bn, const float* scale, const float* shift,
+                                            const float* save_mean, const float* save_invstd, float* part,
+                                            int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    const char* who = "fea_upconv2x2_bwd_data_bnred";
+    int rc = check_common(who, dy, lddy, w, dx, lddx, N, H, W, Cout, Cin, dtype);
+    if (rc) return rc;
+    FEA_CHECK(dtype == FEA_BF16, FEA_E_UNSUPPORTED_SHAPE, "%s: bf16 only (fp32: fea_upconv2x2_bwd_data + fea_bn_relu_bwd_reduce)", who);
+    FEA_CHECK(lddx >= Cin && y && scale && shift && save_mean && save_invstd && part, FEA_E_BADARG, "%s: bad args", who);
+    FEA_CHECK(ldy_bn >= Cin && ldy_bn % 8 == 0 && ((uintptr_t)y % 16 == 0), FEA_E_BADARG, "%s: y layout", who);
+    FEA_CHECK((long long)4 * H * W * lddy < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "%s: image too large", who);
+    IgemmArgs a{};
+    a.x = dy; a.w = w; a.bias = nullptr; a.y = dx; a.stats = nullptr;
+    a.ldx = lddy; a.ldy = lddx; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin; a.Cup = Cin;
+    a.x_img_stride = (long long)4 * H * W * lddy; a.y_img_stride = (long long)H * W * lddx;
+    a.ybn = y; a.ldybn = ldy_bn; a.bn_scale = scale; a.bn_shift = shift; a.bn_mean = save_mean; a.bn_invstd = save_invstd;
+    a.red_part = part;
+    return launch_igemm<__bf16, 2, 2>(a, N, (hipStream_t)stream);
+}
+
 extern "C" int fea_conv3x3_first(const float* x, const void* w_packed, const float* bias, void* y, int ldy, float* stats,
                                  int N, int C, int H, int W, int Cout, int dtype, void* stream) {
     FEA_CHECK(dtype == FEA_BF16, FEA_E_UNSUPPORTED_SHAPE, "fea_conv3x3_first: bf16 only (fp32: fea_im2col3x3_nchw + fea_conv1x1)");

@@ -505,11 +505,11 @@ class UNetEngine:
                    pl.bncoef, dY, pl.part, N, h, w, c, code, S)
             L.call("fea_reduce_partials", pl.part, nblk, c, 0, g[name + ".bias"], S)
 
-        def block_bwd(blk, da_full, ld_da, dpool, inp, ld_in, cin, d_in, ld_din, din_stats=None):
+        def block_bwd(blk, da_full, ld_da, dpool, inp, ld_in, cin, d_in, ld_din, din_stats=None, reduced_tiles=0):
             h, w = pl.dims[LEVEL[blk]]
             c = CH[blk]
             n3, n0 = f"{blk}.3", f"{blk}.0"
-            bn_bwd(n3, da_full, ld_da, dpool, h, w, c)
+            bn_bwd(n3, da_full, ld_da, dpool, h, w, c, reduced_tiles=reduced_tiles)
             dy3 = ring["dY"]
 
             def wg3():
@@ -546,22 +546,31 @@ class UNetEngine:
         L.call("fea_head_bwd_finalize", pl.head_part, nblk, g["out.weight"], g["out.bias"], 64, self.num_classes, S)
         done("out.weight", "out.bias")
         # decoder
+        pre = 0          # > 0: pl.part holds the BN-backward partial sums of the next block's X.3 layer
         for k in (1, 2, 3, 4):
             blk = f"dec{k}"
             c = CH[blk]
             # the dgrad that writes dcat[k] also emits per-tile channel sums of it: channels
             # [0,c) summed over pixels = the transposed conv's bias gradient
-            block_bwd(blk, pl.G[0], c, None, pl.cat[k], 2 * c, 2 * c, pl.dcat[k], 2 * c, din_stats=pl.stats)
+            block_bwd(blk, pl.G[0], c, None, pl.cat[k], 2 * c, 2 * c, pl.dcat[k], 2 * c, din_stats=pl.stats, reduced_tiles=pre)
             hl, wl = pl.dims[k]
             src = pl.a3[f"dec{k + 1}"] if k < 4 else pl.a3["bottleneck"]
             L.call("fea_reduce_partials_n", pl.stats, L.call("fea_conv_num_tiles", N, 2 * hl, 2 * wl), 2 * c, c, 0,
                    g[f"upconv{k}.bias"], S)
             wgrad("fea_upconv2x2_wgrad", (src, 2 * c, pl.dcat[k], 2 * c, g[f"upconv{k}.weight"], pl.ws, pl.ws_bytes,
                                           N, hl, wl, 2 * c, c, code), (f"upconv{k}.weight", f"upconv{k}.bias"), reads_dY=False)
-            L.call("fea_upconv2x2_bwd_data", pl.dcat[k], 2 * c, self._w_up(f"upconv{k}", 1), pl.G[0], 2 * c,
-                   N, hl, wl, 2 * c, c, code, S)
+            if fuse:
+                nxt = f"dec{k + 1}.3" if k < 4 else "bottleneck.3"
+                cfn = pl.coef[nxt]
+                L.call("fea_upconv2x2_bwd_data_bnred", pl.dcat[k], 2 * c, self._w_up(f"upconv{k}", 1), pl.G[0], 2 * c,
+                       pl.y[nxt], 2 * c, cfn["scale"], cfn["shift"], cfn["mean"], cfn["invstd"], pl.part,
+                       N, hl, wl, 2 * c, c, code, S)
+                pre = L.call("fea_conv_num_tiles", N, hl, wl)
+            else:
+                L.call("fea_upconv2x2_bwd_data", pl.dcat[k], 2 * c, self._w_up(f"upconv{k}", 1), pl.G[0], 2 * c,
+                       N, hl, wl, 2 * c, c, code, S)
         # bottleneck and encoder
-        block_bwd("bottleneck", pl.G[0], 1024, None, pl.pool[4], 512, 512, pl.G[1], 512)
+        block_bwd("bottleneck", pl.G[0], 1024, None, pl.pool[4], 512, 512, pl.G[1], 512, reduced_tiles=pre)
         cur = 1
         for k in (4, 3, 2, 1):
             blk = ENC[k - 1]

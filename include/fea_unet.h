@@ -133,6 +133,14 @@ int fea_upconv2x2_fwd(const void* x, int ldx, const void* w_packed, const float*
 /* dx[n,i,j,ci] = sum_{a,b,co} dy[n,2i+a,2j+b,co] w[ci,co,a,b]; (H,W) = dx dims. */
 int fea_upconv2x2_bwd_data(const void* dy, int lddy, const void* w_packed, void* dx, int lddx,
                            int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* fea_upconv2x2_bwd_data fused with the first pass of the BatchNorm backward of the layer that
+ * FEEDS the transposed conv (conv -> BN -> ReLU, models.py:31-33): also writes
+ * part[pixel tile][Cin][2] = per-tile (sum g, sum g*xhat), g = dx * (relu(bn(y)) > 0), exactly
+ * as fea_conv3x3_dgrad_bnred does (rows: fea_conv_num_tiles(N,H,W)).  bf16 only. */
+int fea_upconv2x2_bwd_data_bnred(const void* dy, int lddy, const void* w_packed, void* dx, int lddx,
+                                 const void* y, int ldy_bn, const float* scale, const float* shift,
+                                 const float* save_mean, const float* save_invstd, float* part,
+                                 int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
 
 /* ---- weight gradients (MFMA, split over pixels, deterministic) ----------- */
 

@@ -268,6 +268,39 @@ def test_enc1_im2col_path(dt, cin):
     check(dW, wz.grad, dt, "enc1.0 wgrad")
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16, 128, 64), (1, 8, 24, 256, 128), (1, 2, 2, 1024, 512), (2, 32, 32, 64, 64), (1, 40, 24, 128, 64)])
+def test_upconv2x2_bwd_data_with_fused_bn_backward_reduction(shape):
+    """fea_upconv2x2_bwd_data_bnred == fea_upconv2x2_bwd_data followed by fea_bn_relu_bwd_reduce:
+    identical dx (bit for bit) and the same per-channel sums."""
+    n, h, w, ci, co = shape
+    dt = torch.bfloat16
+    code = L.dt_code(dt)
+    g = torch.Generator().manual_seed(17)
+    wt = (torch.randn(ci, co, 2, 2, generator=g) / ci ** 0.5).to(dt).float()
+    dy = rnd(dt, n, co, 2 * h, 2 * w, gen=g)
+    y = rnd(dt, n, ci, h, w, gen=g)
+    scale, shift = torch.randn(ci, generator=g), torch.randn(ci, generator=g)
+    mean, invstd = torch.randn(ci, generator=g), torch.rand(ci, generator=g) + 0.5
+    coef = [t.to(DEV) for t in (scale, shift, mean, invstd)]
+    dyd = to_nhwc(dy, dt, ld=2 * co, off=0)
+    yd = to_nhwc(y, dt)
+    wpb = torch.empty(4 * ci * co, dtype=dt, device=DEV)
+    L.call("fea_pack_upconv2x2", wt.to(DEV), wpb, ci, co, 1, code, S())
+    dx_ref = torch.full((n, h, w, ci), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_upconv2x2_bwd_data", dyd, 2 * co, wpb, dx_ref, ci, n, h, w, ci, co, code, S())
+    nblk = L.call("fea_bn_bwd_blocks", n, h, w, ci)
+    part_ref = torch.zeros(nblk, ci, 2, device=DEV)
+    L.call("fea_bn_relu_bwd_reduce", dx_ref, ci, None, yd, *coef, part_ref, n, h, w, ci, code, S())
+    ntiles = L.call("fea_conv_num_tiles", n, h, w)
+    dx = torch.full((n, h, w, ci), float("nan"), dtype=dt, device=DEV)
+    part = torch.full((ntiles, ci, 2), float("nan"), device=DEV)
+    L.call("fea_upconv2x2_bwd_data_bnred", dyd, 2 * co, wpb, dx, ci, yd, ci, *coef, part, n, h, w, ci, co, code, S())
+    torch.cuda.synchronize()
+    assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16)), "fused kernel changed the data gradient"
+    got, ref = part.double().sum(0).cpu(), part_ref.double().sum(0).cpu()
+    assert rel_l2(got, ref) < 1e-5, f"fused BN-backward sums: {rel_l2(got, ref):.3e}"
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 16, 16, 128, 64), (1, 8, 24, 256, 128), (1, 2, 2, 1024, 512), (2, 32, 32, 64, 64)])
 def test_upconv2x2(dt, shape):
