@@ -369,7 +369,7 @@ class UNetEngine:
                        B[bn + ".running_var"], BN_EPS, cf["scale"], cf["shift"], cout, S)
             L.call("fea_bn_relu_pool", y, cf["scale"], cf["shift"], out_full, ld_full, out_pool, N, h, w, cout, code, S)
 
-        es = x.element_size() if False else torch.empty(0, dtype=self.dtype).element_size()
+        es = torch.empty(0, dtype=self.dtype).element_size()
 
         def off_ptr(t: torch.Tensor, ch_off: int) -> int:
             return t.data_ptr() + ch_off * es
