@@ -147,20 +147,34 @@ __global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __r
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
-// part[blk][4]; blk = (plane * chunks + chunk); plane = n*C + c
+// One element of the loss sums.  e = exp(-|x|) serves both the stable BCE term
+// max(x,0) - x t + log1p(e) and the sigmoid (1/(1+e) for x >= 0, e/(1+e) otherwise).
+__device__ __forceinline__ void loss_terms(float v, float tt, float& sb, float& si, float& sp, float& st) {
+    const float e = expf(-fabsf(v));
+    const float r = 1.f / (1.f + e);
+    const float p = v >= 0.f ? r : e * r;
+    sb += fmaxf(v, 0.f) - v * tt + log1pf(e);
+    si += p * tt; sp += p; st += tt;
+}
+
+// part[blk][4]; blk = (plane * chunks + chunk); plane = n*C + c.  VEC = 4: 16-byte logit loads
+// and 4-byte target loads (HW % 4 == 0 and aligned bases), VEC = 1: any shape.
+template <int VEC>
 __global__ __launch_bounds__(256) void bce_dice_sums_kernel(const float* __restrict__ x, const uint8_t* __restrict__ t,
                                                             float* __restrict__ part, long long HW, int chunks, long long chunk_len) {
     const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
     const long long b = (long long)plane * HW;
     const long long i0 = chunk * chunk_len, i1 = i0 + chunk_len < HW ? i0 + chunk_len : HW;
     float sb = 0.f, si = 0.f, sp = 0.f, st = 0.f;
-    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-        const float v = x[b + i];
-        const float tt = t[b + i] ? 1.f : 0.f;
-        // stable BCE-with-logits: max(x,0) - x*t + log1p(exp(-|x|))
-        sb += fmaxf(v, 0.f) - v * tt + log1pf(expf(-fabsf(v)));
-        const float p = 1.f / (1.f + expf(-v));
-        si += p * tt; sp += p; st += tt;
+    if constexpr (VEC == 4) {
+        for (long long i = i0 + threadIdx.x * 4; i < i1; i += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + b + i);
+            const uint32_t tw = *reinterpret_cast<const uint32_t*>(t + b + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) loss_terms(v[k], ((tw >> (8 * k)) & 0xff) ? 1.f : 0.f, sb, si, sp, st);
+        }
+    } else {
+        for (long long i = i0 + threadIdx.x; i < i1; i += 256) loss_terms(x[b + i], t[b + i] ? 1.f : 0.f, sb, si, sp, st);
     }
     __shared__ float sh[4][4];
     float vals[4] = {sb, si, sp, st};
@@ -197,6 +211,7 @@ __global__ __launch_bounds__(256) void bce_dice_sums_finalize_kernel(const float
     if (threadIdx.x < 4) sums[c * 4 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void bce_dice_grad_kernel(const float* __restrict__ x, const uint8_t* __restrict__ t,
                                                             const double* __restrict__ sums, float* __restrict__ loss,
                                                             float* __restrict__ dx, float gscale, int N, int C, long long HW) {
@@ -209,18 +224,31 @@ __global__ __launch_bounds__(256) void bce_dice_grad_kernel(const float* __restr
         }
         loss[0] = (float)(bce / (double)total + 1.0 - dice / C);
     }
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
     if (i >= total || !dx) return;
-    const int c = (int)((i / HW) % C);
+    const int c = (int)((i / HW) % C);            // VEC elements never straddle a plane (HW % VEC == 0)
     const double I = sums[c * 4 + 1], S = sums[c * 4 + 2] + sums[c * 4 + 3];
-    const float v = x[i];
-    const float tt = t[i] ? 1.f : 0.f;
-    const float p = 1.f / (1.f + expf(-v));
     const float inv = (float)(1.0 / (S + 1.0));
-    // d dice_c / d p = (2 t (S+1) - (2I+1)) / (S+1)^2
-    const float ddice = (2.f * tt - (float)((2.0 * I + 1.0) / (S + 1.0))) * inv;
-    const float g = (p - tt) / (float)total - ddice * p * (1.f - p) / (float)C;
-    dx[i] = g * gscale;
+    const float k2 = (float)((2.0 * I + 1.0) / (S + 1.0));
+    const float itot = 1.f / (float)total, ic = 1.f / (float)C;
+    auto grad = [&](float v, float tt) {
+        const float e = expf(-fabsf(v));
+        const float r = 1.f / (1.f + e);
+        const float p = v >= 0.f ? r : e * r;
+        // d dice_c / d p = (2 t (S+1) - (2I+1)) / (S+1)^2
+        const float ddice = (2.f * tt - k2) * inv;
+        return ((p - tt) * itot - ddice * p * (1.f - p) * ic) * gscale;
+    };
+    if constexpr (VEC == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        const uint32_t tw = *reinterpret_cast<const uint32_t*>(t + i);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = grad(v[k], ((tw >> (8 * k)) & 0xff) ? 1.f : 0.f);
+        *reinterpret_cast<f32x4*>(dx + i) = o;
+    } else {
+        dx[i] = grad(x[i], t[i] ? 1.f : 0.f);
+    }
 }
 
 __global__ __launch_bounds__(256) void mask_iou_kernel(const float* __restrict__ x, const uint8_t* __restrict__ t,
@@ -327,7 +355,9 @@ extern "C" int fea_bce_dice_sums(const float* logits, const uint8_t* target, dou
     FEA_CHECK(logits && target && sums && part && N > 0 && Ccls > 0 && HW > 0, FEA_E_BADARG, "fea_bce_dice_sums: bad args");
     int chunks; long long cl; loss_plan(HW, chunks, cl);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bce_dice_sums_kernel, dim3(N * Ccls * chunks), dim3(256), 0, s, logits, target, part, HW, chunks, cl);
+    const bool vec = HW % 4 == 0 && (uintptr_t)logits % 16 == 0 && (uintptr_t)target % 4 == 0;
+    if (vec) hipLaunchKernelGGL(bce_dice_sums_kernel<4>, dim3(N * Ccls * chunks), dim3(256), 0, s, logits, target, part, HW, chunks, cl);
+    else     hipLaunchKernelGGL(bce_dice_sums_kernel<1>, dim3(N * Ccls * chunks), dim3(256), 0, s, logits, target, part, HW, chunks, cl);
     FEA_LAUNCH_CHECK();
     hipLaunchKernelGGL(bce_dice_sums_finalize_kernel, dim3(Ccls), dim3(256), 0, s, part, sums, N, Ccls, chunks);
     FEA_LAUNCH_CHECK();
@@ -338,9 +368,13 @@ extern "C" int fea_bce_dice_grad(const float* logits, const uint8_t* target, con
                                  float gscale, int N, int Ccls, long long HW, void* stream) {
     FEA_CHECK(logits && target && sums && (loss || dlogits) && N > 0 && Ccls > 0 && HW > 0, FEA_E_BADARG, "fea_bce_dice_grad: bad args");
     const long long total = (long long)N * Ccls * HW;
-    const long long nb = dlogits ? (total + 255) / 256 : 1;
-    hipLaunchKernelGGL(bce_dice_grad_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, logits, target, sums, loss, dlogits,
-                       gscale, N, Ccls, HW);
+    const bool vec = HW % 4 == 0 && (uintptr_t)logits % 16 == 0 && (uintptr_t)target % 4 == 0 && (!dlogits || (uintptr_t)dlogits % 16 == 0);
+    const long long per = vec ? 1024 : 256;
+    const long long nb = dlogits ? (total + per - 1) / per : 1;
+    if (vec) hipLaunchKernelGGL(bce_dice_grad_kernel<4>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, logits, target, sums, loss, dlogits,
+                                gscale, N, Ccls, HW);
+    else     hipLaunchKernelGGL(bce_dice_grad_kernel<1>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, logits, target, sums, loss, dlogits,
+                                gscale, N, Ccls, HW);
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }

@@ -42,6 +42,11 @@ def main():
     def apply(s):
         L.call("fea_bn_relu_bwd_apply", da, c, None, y, *coef, bncoef, out, part, n, h, w, c, code, s.cuda_stream)
 
+    sc, sh = torch.randn(c, device=dev), torch.randn(c, device=dev)
+
+    def bnfwd(s):       # 28 VGPRs: several waves fit beside the MFMA kernels
+        L.call("fea_bn_relu_pool", y, sc, sh, out, c, None, n, h, w, c, code, s.cuda_stream)
+
     def timed(fa, fb, reps=10):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -60,11 +65,12 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    for name, f in (("wgrad", wgrad), ("conv", conv)):
-        timed(f, apply, 3)
-        a, b, ab = timed(f, None), timed(None, apply), timed(f, apply)
-        print(f"{name}: alone {a:.3f} ms   apply alone {b:.3f} ms   serial {a + b:.3f}   concurrent {ab:.3f}   "
-              f"hidden {(a + b - ab) / b * 100:.0f} % of apply")
+    for sname, sf in (("bn_bwd_apply", apply), ("bn_relu_fwd", bnfwd)):
+        for name, f in (("wgrad", wgrad), ("conv", conv)):
+            timed(f, sf, 3)
+            a, b, ab = timed(f, None), timed(None, sf), timed(f, sf)
+            print(f"{name} + {sname}: alone {a:.3f} ms / {b:.3f} ms   serial {a + b:.3f}   concurrent {ab:.3f}   "
+                  f"hidden {(a + b - ab) / b * 100:.0f} % of the streaming kernel")
 
 
 if __name__ == "__main__":

@@ -443,7 +443,7 @@ def test_head_forward_backward(dt, ncls):
     assert rel_l2(db.cpu(), br.grad) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(2, 6, 32, 48), (1, 1, 16, 16), (3, 6, 128, 96)])
+@pytest.mark.parametrize("shape", [(2, 6, 32, 48), (1, 1, 16, 16), (3, 6, 128, 96), (2, 3, 5, 7)])
 def test_loss_mask_iou(shape):
     """BCE+Dice loss and its gradient within fp32 tolerance; mask and IoU
     counts BIT-EXACT (integer work) against torch boolean ops on identical logits."""

@@ -50,7 +50,7 @@ def run_hip(m, x, dl):
     return lg.detach().cpu(), {k: v.cpu() for k, v in taps.items()}
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 32), (1, 64, 48), (3, 16, 16)])
+@pytest.mark.parametrize("shape", [(2, 32, 32), (1, 64, 48), (3, 16, 16), (1, 128, 96)])
 def test_fp32_forward_backward_buffers(shape):
     n, h, w = shape
     m, params, bufs = make(10, "fp32")
@@ -84,7 +84,7 @@ def test_fp32_forward_backward_buffers(shape):
     assert rel_l2(le, lo_e) < 1e-4 and max_rel(le, lo_e) < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 32), (4, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 32, 32), (4, 64, 64), (2, 256, 192)])
 def test_bf16_forward_backward(shape):
     n, h, w = shape
     m, params, bufs = make(11, "bf16")
@@ -95,8 +95,18 @@ def test_bf16_forward_backward(shape):
     lg, taps = run_hip(m, x, dl)
     lo, go, nb = O.grads_from_dlogits(params, bufs, x, dl, forced=O.forced_from_taps(taps))
     assert rel_l2(lg, lo) < 3e-2
-    errs = sorted(rel_l2(p.grad, go[k]) for k, p in m.named_parameters() if not cancelled(k))
+    # upconvK.bias is NEARLY cancelled: a constant added to the up-sampled half of the concat
+    # shifts dec_K.0's output by a constant away from the image border, which its BatchNorm
+    # removes -- only border pixels contribute, the rest of the pixel sum cancels, and the bf16
+    # rounding of the summed gradients does not (27 % of a 4e-4 gradient at 256x192).  It is
+    # compared on the scale of the same layer's weight gradient; the fp32 test pins it to 1e-4.
+    near = lambda k: k.startswith("upconv") and k.endswith(".bias")
+    errs = sorted(rel_l2(p.grad, go[k]) for k, p in m.named_parameters() if not cancelled(k) and not near(k))
     assert errs[-1] < 1.5e-1 and errs[len(errs) // 2] < 5e-2, (errs[-1], errs[len(errs) // 2])
+    for k, p in m.named_parameters():
+        if near(k):
+            scale = go[k.replace(".bias", ".weight")].norm().item()
+            assert (p.grad.cpu() - go[k]).norm().item() < 1e-2 * scale, k
     for k, b in m.named_buffers():
         if not k.endswith("num_batches_tracked"):
             assert rel_l2(b, nb[k]) < 3e-2, k
