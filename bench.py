@@ -179,8 +179,9 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"UNet (FloorPlanSegmentationModel) training step, {a.size}x{a.size}, batch {a.batch}/GPU, "
-                                   f"{a.dtype} storage / fp32 accumulate, BCE+Dice loss, clip 1.0, AdamW (BASELINE configs[2]"
-                                   f"{'/[3]' if world > 1 else ''})",
+                                   f"{a.dtype} storage / fp32 accumulate, BCE+Dice loss, clip 1.0, AdamW"
+                                   + (f" (BASELINE configs[2]{'/[3]' if world > 1 else ''})" if (a.batch, a.size, a.dtype) == (64, 512, "bf16")
+                                      else (" (BASELINE configs[1])" if (a.batch, a.size, a.dtype) == (16, 256, "fp32") else "")),
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "per_gpu_batch": a.batch},
             "whole_step_tflops_per_gpu": ips / world * gf / 1e3,
             "whole_step_mfma_frac": ips / world * gf / 1e3 / (PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS),
