@@ -60,6 +60,62 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a, 
     }
 }
 
+// Four consecutive pixels per 8-lane group (HW % 4 == 0): four 16-byte loads in flight per
+// lane, and after a halving exchange (xor 4, 2, 1: each step a lane keeps half of its
+// classes and adds the partner's partial sums of them) lane `sub` holds class `sub` of the
+// four pixels and stores them as one float4 -- 128 contiguous bytes per plane per wave.
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd4_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ logits,
+                                                        long long nquad, long long HW, int Ccls) {
+    __shared__ float ws[8 * 64 + 8];
+    for (int i = threadIdx.x; i < 8 * 64; i += 256) ws[i] = i < Ccls * 64 ? w[i] : 0.f;
+    if (threadIdx.x < 8) ws[8 * 64 + threadIdx.x] = threadIdx.x < Ccls ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const int sub = threadIdx.x & 7;
+    const float bsub = ws[8 * 64 + sub];
+    const long long stride = (long long)gridDim.x * 32;
+    for (long long q = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); q < nquad; q += stride) {
+        const long long p0 = q * 4;
+        float f[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load8<T>(a + (p0 + k) * lda + sub * 8, f[k]);
+        float v[8][4];
+        int woff = sub * 8;
+        asm volatile("" : "+v"(woff));         // opaque: the weight reads stay in the loop (64 fewer live registers)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float wr[8];                       // this lane's 8 weights of class c
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wr[j] = ws[c * 64 + woff + j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s_ = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s_ = __builtin_fmaf(f[k][j], wr[j], s_);
+                v[c][k] = s_;
+            }
+        }
+        float v4[4][4], v2[2][4], v1[4];
+        const bool b4 = sub & 4, b2 = sub & 2, b1 = sub & 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v4[c][k] = (b4 ? v[c + 4][k] : v[c][k]) + __shfl_xor(b4 ? v[c][k] : v[c + 4][k], 4);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v2[c][k] = (b2 ? v4[c + 2][k] : v4[c][k]) + __shfl_xor(b2 ? v4[c][k] : v4[c + 2][k], 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v1[k] = (b1 ? v2[1][k] : v2[0][k]) + __shfl_xor(b1 ? v2[0][k] : v2[1][k], 1);
+        if (sub < Ccls) {
+            const long long n = p0 / HW, hw = p0 - n * HW;
+            f32x4 o = {v1[0] + bsub, v1[1] + bsub, v1[2] + bsub, v1[3] + bsub};
+            *reinterpret_cast<f32x4*>(logits + (n * Ccls + sub) * HW + hw) = o;
+        }
+    }
+}
+
 // da = W^T dl ; partial dW / db.  part[blk][c*65 + k], k = 64 -> db.
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const T* __restrict__ a, int lda,
@@ -84,6 +140,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         const long long n = p / HW, hw = p - n * HW;
         float f[8], o[8];
         load8<T>(a + p * lda + sub * 8, f);
+        int woff = sub * 8;
+        asm volatile("" : "+v"(woff));         // opaque: the weight reads stay in the loop (64 fewer live registers, 2x the waves)
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = 0.f;
 #pragma unroll
@@ -92,7 +150,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             gb[c] += d;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                o[j] = __builtin_fmaf(d, ws[c * 64 + sub * 8 + j], o[j]);
+                o[j] = __builtin_fmaf(d, ws[c * 64 + woff + j], o[j]);
                 gw[c][j] = __builtin_fmaf(d, f[j], gw[c][j]);
             }
         }
@@ -300,7 +358,9 @@ extern "C" int fea_head_fwd(const void* a, int lda, const float* w, const float*
     const long long npix = (long long)N * H * W, HW = (long long)H * W;
     const int nblk = head_blocks(npix);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == FEA_BF16) {
+    if (dtype == FEA_BF16 && Ccls <= 8 && HW % 4 == 0 && (uintptr_t)logits % 16 == 0) {
+        hipLaunchKernelGGL((head_fwd4_kernel<__bf16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, logits, npix / 4, HW, Ccls);
+    } else if (dtype == FEA_BF16) {
         if (Ccls <= 8) hipLaunchKernelGGL((head_fwd_kernel<__bf16, 8>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, logits, npix, HW, Ccls);
         else hipLaunchKernelGGL((head_fwd_kernel<__bf16, 16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, logits, npix, HW, Ccls);
     } else if (dtype == FEA_F32) {
