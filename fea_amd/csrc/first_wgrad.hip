@@ -27,8 +27,8 @@ struct FirstWgradArgs {
 
 constexpr int FW_HALO = 10 * 34;                 // floats per channel
 constexpr int FW_DY_BYTES = 256 * 128;
-constexpr int FW_X_BYTES = 10 * 1024;            // >= 7 * 340 * 4
-constexpr int FW_STAGE = FW_DY_BYTES + FW_X_BYTES;
+// halo region of a stage: XB = 4 KB for C <= 3 (3 * 340 * 4 = 4080 B: two 36 KB stages, two
+// workgroups per CU), 10 KB up to C = 7
 
 // 32-byte unit swizzle of the dy rows: rows read together by one ds_read_b64_tr_b16
 // half-wave ({x..x+3} and {x+8..x+11}, same 32-byte channel block) land in distinct banks
@@ -69,6 +69,7 @@ __device__ __forceinline__ void fw_issue(const FirstWgradArgs& g, int m0, int wa
 // Multiply the tile resident in `rd` (rows ty = wave, wave + 4) while the LDS-DMA of the
 // next tile lands in `dma`.  __restrict__ on purpose: see wgrad2.hip (keeps hipcc from
 // draining vmcnt before every LDS read).
+template <int XB>
 __device__ __forceinline__ void fw_step(const FirstWgradArgs& g, int m0, int wave, int lane, int next_tile,
                                         char* __restrict__ dma, const char* __restrict__ rd,
                                         const int (&xdesc)[10], int nxi, const int (&boff)[4], int NT, f32x4 (&acc)[4][4]) {
@@ -107,7 +108,10 @@ __device__ __forceinline__ void fw_step(const FirstWgradArgs& g, int m0, int wav
     }
 }
 
+template <int XB>
 __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstWgradArgs g) {
+    constexpr int FW_STAGE = FW_DY_BYTES + XB;
+    static_assert(2 * FW_STAGE >= 4 * 64 * 64 * 4, "the epilogue sums four 64 x 64 fp32 tiles through LDS");
     __shared__ __attribute__((aligned(128))) char smem[2 * FW_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstWgradArgs g
         const int stage = (tile - t_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                 // tile landed; the other stage is free
-        fw_step(g, m0, wave, lane, tile + 1 < t_end ? tile + 1 : -1, smem + (stage ^ 1) * FW_STAGE, smem + stage * FW_STAGE,
+        fw_step<XB>(g, m0, wave, lane, tile + 1 < t_end ? tile + 1 : -1, smem + (stage ^ 1) * FW_STAGE, smem + stage * FW_STAGE,
                 xdesc, nxi, boff, NT, acc);
     }
     __syncthreads();
@@ -210,7 +214,8 @@ extern "C" int fea_conv3x3_first_wgrad(const void* dy, int lddy, const float* x,
     a.dy = (const __bf16*)dy; a.x = x; a.slab = (float*)ws; a.lddy = lddy; a.C = C; a.H = H; a.W = W; a.Cout = Cout;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(first_wgrad_kernel, dim3((unsigned)p.splits, (unsigned)(Cout / 64)), dim3(256), 0, s, a);
+    if (C <= 3) hipLaunchKernelGGL(first_wgrad_kernel<4096>, dim3((unsigned)p.splits, (unsigned)(Cout / 64)), dim3(256), 0, s, a);
+    else        hipLaunchKernelGGL(first_wgrad_kernel<10240>, dim3((unsigned)p.splits, (unsigned)(Cout / 64)), dim3(256), 0, s, a);
     FEA_LAUNCH_CHECK();
     const int total = Cout * 9 * C;
     hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,

@@ -8,8 +8,8 @@
 // chosen to stage each byte as few times as possible: one 512-thread workgroup owns
 // 128 input channels x 64 output channels x all 4 taps and walks a range of 4x16-pixel
 // (low-res) tiles.  Per tile, two 64-channel halves of x and the four tap images of dy
-// (64 pixels x 64 channels each, 128-byte rows) are brought in by LDS-DMA into a two-stage
-// ring.  Wave w = (x half, tap) multiplies a 64 x 64 block: transposing LDS reads
+// (64 pixels x 64 channels each, 128-byte rows) are brought in by LDS-DMA into a three-stage
+// ring (two tiles in flight: the op is latency-bound with one).  Wave w = (x half, tap) multiplies a 64 x 64 block: transposing LDS reads
 // (ds_read_b64_tr_b16) feed v_mfma_f32_32x32x16_bf16, reduction step = one 16-pixel tile row.
 // Workgroups write fp32 slabs in the parameter's own [ci][co][2][2] order; the slabs are
 // summed in a fixed order by wgrad2_reduce_kernel (deterministic).
@@ -81,7 +81,7 @@ __device__ __forceinline__ void wu_step(const WgradUpArgs& g, int m0, int n0, in
 }
 
 __global__ __launch_bounds__(512, 2) void wgrad_up_kernel(const WgradUpArgs g) {
-    __shared__ __attribute__((aligned(128))) char smem[2 * WU_STAGE];
+    __shared__ __attribute__((aligned(128))) char smem[3 * WU_STAGE];   // three-stage ring: two tiles in flight
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -115,11 +115,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_up_kernel(const WgradUpArgs g) {
     const int t_begin = split * g.tiles_per_split;
     const int t_end = min(t_begin + g.tiles_per_split, g.ntiles);
     if (t_begin < t_end) wu_issue(g, m0, n0, wave, lane, t_begin, smem);
+    if (t_begin + 1 < t_end) wu_issue(g, m0, n0, wave, lane, t_begin + 1, smem + WU_STAGE);
+    int stage = 0;
     for (int tile = t_begin; tile < t_end; ++tile) {
-        const int stage = (tile - t_begin) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                 // tile landed; the other stage is free
-        wu_step(g, m0, n0, wave, lane, tile + 1 < t_end ? tile + 1 : -1, smem + (stage ^ 1) * WU_STAGE, smem + stage * WU_STAGE, col, acc);
+        // LDS-DMA loads retire in order: all but the six of tile + 1 have landed
+        if (tile + 1 < t_end) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // tile landed; the stage read in the previous iteration is free
+        const int dma = stage >= 1 ? stage - 1 : 2;       // (stage + 2) % 3
+        wu_step(g, m0, n0, wave, lane, tile + 2 < t_end ? tile + 2 : -1, smem + dma * WU_STAGE, smem + stage * WU_STAGE, col, acc);
+        stage = stage == 2 ? 0 : stage + 1;
     }
     // out[(m0 + mh*64 + row)][n0 + col][tap]
     const int mh = wave >> 2, tap = wave & 3;
