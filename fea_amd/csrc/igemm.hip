@@ -545,29 +545,42 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
             const int col = cout0 + wn * 64 + n * 16 + r16;
             bv[n] = g.bias ? g.bias[EPI == 1 ? col % g.Cup : col] : 0.f;
         }
+        // (vector adds / fmas: v_pk_add_f32, v_pk_fma_f32 -- the epilogue is VALU-issue bound on the
+        // 64- and 128-channel layers, where it is a quarter of a workgroup's life)
 #pragma unroll
         for (int m = 0; m < MT16; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < 4; ++n) {
+                const f32x4 b4 = {bv[n], bv[n], bv[n], bv[n]};
+                acc16[m][n] += b4;
+                if constexpr (EPI == 3) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc16[m][n][j] = EPI == 3 ? fmaxf(acc16[m][n][j] + bv[n], 0.f) : acc16[m][n][j] + bv[n];
+                    for (int j = 0; j < 4; ++j) acc16[m][n][j] = fmaxf(acc16[m][n][j], 0.f);
+                }
+            }
 
         if (EPI == 0 && g.stats) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                float s = 0.f, q = 0.f;
+                float s, q;
+                if (full) {
+                    f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int m = 0; m < MT16; ++m)
+                    for (int m = 0; m < MT16; ++m) { s4 += acc16[m][n]; q4 = __builtin_elementwise_fma(acc16[m][n], acc16[m][n], q4); }
+                    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                    q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+                } else {
+                    s = 0.f; q = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = acc16[m][n][j];
-                        if (!full) {
+                    for (int m = 0; m < MT16; ++m)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
                             const int p = wm * (MT * 32) + m * 16 + 4 * q16 + j;
                             const bool ok = (y0 + (p >> tws) < H) && (x0 + (p & (TW - 1)) < W);
-                            v = ok ? v : 0.f;
+                            const float v = ok ? acc16[m][n][j] : 0.f;
+                            s += v; q += v * v;
                         }
-                        s += v; q += v * v;
-                    }
+                }
                 s = row_sum4(s); q = row_sum4(q);
                 if (q16 == 0) {
                     st[(wm * BN + wn * 64 + n * 16 + r16) * 2 + 0] = s;
