@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 import torch
 
@@ -17,7 +17,7 @@ F32, BF16 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FEA_AMD_LIB") or os.path.join(_HERE, "libfea_unet.so")   # env override: A/B builds in scripts/
 
-P, I, L, F, Z = c_void_p, c_int, c_longlong, c_float, c_size_t
+P, I, L, F, Z, D = c_void_p, c_int, c_longlong, c_float, c_size_t, c_double
 
 # name -> (restype, argtypes); mirrors include/fea_unet.h one to one.
 SIGNATURES = {
@@ -65,6 +65,10 @@ SIGNATURES = {
     "fea_bce_dice_grad": (I, [P, P, P, P, P, F, I, I, L, P]),
     "fea_mask_iou": (I, [P, P, P, P, P, I, I, L, P]),
     "fea_binarise": (I, [P, P, L, P]),
+    "fea_opt_chunk": (I, []),
+    "fea_sumsq_blocks": (I, [L]),
+    "fea_grad_sumsq": (I, [P, L, P, P, P]),
+    "fea_adamw_clip_step": (I, [P, I, P, P, P, P, D, D, D, D, D, D, I, P]),
     "fea_resize_ksize": (I, [I, I]),
     "fea_resize_coeffs": (I, [I, I, P, P]),
     "fea_normalize_lut": (I, [P, P, I, P]),
@@ -127,7 +131,7 @@ def call(name: str, *args):
     lib = load()
     fn = getattr(lib, name)
     conv = [ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a for a in args]
-    if PROFILE is not None and SIGNATURES[name][1] and SIGNATURES[name][1][-1] is P and not name.endswith(("_blocks", "_tiles")):
+    if PROFILE is not None and SIGNATURES[name][1] and SIGNATURES[name][1][-1] is P and not name.endswith(("_blocks", "_tiles", "_chunk", "_ksize", "_coeffs")):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*conv)
@@ -135,6 +139,6 @@ def call(name: str, *args):
         PROFILE.append((name, e0, e1, conv))
     else:
         rc = fn(*conv)
-    if SIGNATURES[name][0] is I and rc < 0 and not name.endswith(("_blocks", "_tiles")):
+    if SIGNATURES[name][0] is I and rc < 0 and not name.endswith(("_blocks", "_tiles", "_chunk", "_ksize", "_coeffs")):
         raise FeaError(f"{name} failed ({rc}): {lib.fea_last_error().decode()}")
     return rc

@@ -20,6 +20,7 @@ import torch.distributed as dist
 from . import _lib as L
 from . import functional as Fn
 from .engine import param_order
+from .optim import ClipAdamW
 
 
 class GradBuckets:
@@ -91,14 +92,21 @@ class UNetTrainer:
 
     def __init__(self, model, config: Optional[dict] = None, distributed: bool = False, bucket_mb: float = 32.0):
         cfg = dict(learning_rate=1e-4, weight_decay=1e-5, batch_size=4, num_epochs=50, max_grad_norm=1.0,
-                   checkpoint_dir="./checkpoints", log_dir="./logs", save_every=5)
+                   checkpoint_dir="./checkpoints", log_dir="./logs", save_every=5,
+                   optimizer="hip")          # "hip": fea_amd.optim.ClipAdamW (two launches); "torch": torch's fused AdamW
         cfg.update(config or {})
         self.cfg = cfg
         self.model = model
         self.eng = model._engine()
         self.params = list(model.parameters())
         # AdamW(lr, weight_decay) + CosineAnnealingLR(T_max=epochs, eta_min=1e-6): train_direct.py:28-39
-        self.opt = torch.optim.AdamW(self.params, lr=cfg["learning_rate"], weight_decay=cfg["weight_decay"], fused=True)
+        if cfg["optimizer"] == "hip":
+            self.opt = ClipAdamW(list(model.named_parameters()), self.eng, lr=cfg["learning_rate"],
+                                 weight_decay=cfg["weight_decay"], max_grad_norm=cfg["max_grad_norm"])
+        elif cfg["optimizer"] == "torch":
+            self.opt = torch.optim.AdamW(self.params, lr=cfg["learning_rate"], weight_decay=cfg["weight_decay"], fused=True)
+        else:
+            raise ValueError(f"optimizer must be 'hip' or 'torch', got {cfg['optimizer']!r}")
         self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=cfg["num_epochs"], eta_min=1e-6)
         self.loss_ws = {}
         self.buckets = None
@@ -126,6 +134,10 @@ class UNetTrainer:
         self.eng.backward(dl)                     # writes p.grad (views of the flat buffer)
         if self.buckets is not None:
             self.buckets.wait()
+        if isinstance(self.opt, ClipAdamW):
+            # clip_grad_norm_ + AdamW in two launches (train_direct.py:105-106)
+            self.last_grad_norm = self.opt.step()
+            return loss
         # clip_grad_norm_(params, 1.0): train_direct.py:105 -- on the flat buffer (padding is zero)
         flat = self.eng.flat_grad
         total = torch.linalg.vector_norm(flat)

@@ -227,6 +227,23 @@ int fea_mask_iou(const float* logits, const uint8_t* target, uint8_t* mask, long
 int fea_binarise(const uint8_t* grey, uint8_t* out, long long n, void* stream);
 
 
+/* ---- optimiser step --------------------------------------
+ * torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.AdamW.step()
+ * (train_direct.py:28-32,105-106) over the flat gradient buffer, two launches:
+ * fea_grad_sumsq: sumsq[0] (fp64, device) = sum of g[i]^2, i < n; part: fea_sumsq_blocks(n) floats.
+ * fea_adamw_clip_step: seg = DEVICE table [nseg][3] of (parameter chunk address, element offset
+ * of the chunk in g/m/v, element count <= fea_opt_chunk()); the gradient is scaled by
+ * min(1, max_norm / (sqrt(sumsq) + 1e-6)) on the fly (max_norm <= 0: no clipping) and never
+ * rewritten.  AdamW arithmetic as torch.optim.AdamW: p *= 1 - lr*wd; m = lerp(m, g, 1-b1);
+ * v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  Hyper-parameters
+ * are doubles: the derived constants are formed in double as Python does, then rounded to fp32. */
+int fea_opt_chunk(void);
+int fea_sumsq_blocks(long long n);
+int fea_grad_sumsq(const float* g, long long n, float* part, double* sumsq, void* stream);
+int fea_adamw_clip_step(const long long* seg, int nseg, const float* g_flat, float* m_flat, float* v_flat,
+                        const double* sumsq, double max_norm, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, int step, void* stream);
+
 /* ---- input pipeline ------------------------------------------------
  * The reference's per-image transform, custom_dataset.py:23-28 (applied at :69-71):
  * Resize((S,S)) on a PIL image -> ToTensor() -> Normalize(mean, std).  The resize is

@@ -374,3 +374,42 @@ def test_tiled_inference_equals_whole_image(dt):
     # IoU counts are exact for the logits they are computed from
     _, ref_i, ref_u = O.mask_iou_counts(tiled.cpu(), tgt.cpu())
     assert torch.equal(it.cpu(), ref_i) and torch.equal(ut.cpu(), ref_u)
+
+
+def test_hip_optimizer_matches_torch_adamw_and_shares_checkpoints():
+    """clip_grad_norm_(1.0) + AdamW (train_direct.py:28-32,105-106) in two HIP launches
+    (fea_amd.optim.ClipAdamW) against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW on the same
+    gradients; optimizer state_dicts are interchangeable with torch's."""
+    from fea_amd.optim import ClipAdamW
+    torch.manual_seed(21)
+    ma = fea_amd.FloorPlanSegmentationModel(compute_dtype="fp32").cuda()
+    mb = fea_amd.FloorPlanSegmentationModel(compute_dtype="fp32").cuda()
+    mb.load_state_dict(ma.state_dict())
+    eng = ma._engine()
+    eng._ensure_device(torch.zeros(1, device="cuda"))
+    eng._ensure_flat_grad()
+    names = [n for n, _ in ma.named_parameters()]
+    for n, p in ma.named_parameters():
+        p.grad = eng.grad_views[n]
+    oa = ClipAdamW(list(ma.named_parameters()), eng, lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0)
+    ob = torch.optim.AdamW(mb.parameters(), lr=1e-3, weight_decay=1e-2)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for step in range(4):
+        scale = (5.0, 1e-3, 2.0, 0.3)[step]                      # clipped and unclipped steps
+        for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+            gr = torch.randn(pa.shape, device="cuda", generator=g) * scale / pa.numel() ** 0.5
+            eng.grad_views[n].copy_(gr)
+            pb.grad = gr.clone()
+        norm_a = oa.step()
+        norm_b = torch.nn.utils.clip_grad_norm_(mb.parameters(), 1.0)
+        ob.step()
+        assert abs(float(norm_a) - float(norm_b)) <= 2e-6 * float(norm_b)
+        for n, pa, pb in zip(names, ma.parameters(), mb.parameters()):
+            assert torch.allclose(pa, pb, rtol=2e-6, atol=1e-8), (step, n, (pa - pb).abs().max().item())
+        if step == 1:
+            # swap optimizer states through state_dict: ours -> torch's and torch's -> ours
+            sa, sb = oa.state_dict(), ob.state_dict()
+            assert sa["state"][0].keys() == sb["state"][0].keys() and sa["param_groups"][0]["params"] == sb["param_groups"][0]["params"]
+            ob.load_state_dict(sa)
+            oa.load_state_dict(sb)
+    assert oa._t == 4 and float(ob.state[next(iter(mb.parameters()))]["step"]) == 4
