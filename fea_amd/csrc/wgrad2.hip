@@ -43,14 +43,11 @@ __device__ __forceinline__ int swzw2(int x) {      // bit-reverse of bits 1..3 o
 // Issue the LDS-DMA loads of one 256-pixel tile (P rows then Q halo rows) into `sb`.
 template <int TWS>
 __device__ __forceinline__ void wg2_issue(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
-                                          const int (&pdesc)[4], const int (&qdesc)[6], int wave, int tile, char* sb) {
+                                          const int (&pdesc)[4], const int (&qdesc)[6], int wave,
+                                          int tile_x, int tile_y, int n_img, char* sb) {
     constexpr int TW = 1 << TWS, TH = 256 / TW;
     constexpr int QROWS = 352, PBYTES = 256 * 128;
     const int H = g.H, W = g.W;
-    int tt = tile;
-    const int tile_x = tt % g.tiles_x; tt /= g.tiles_x;
-    const int tile_y = tt % g.tiles_y;
-    const int n_img = tt / g.tiles_y;
     const int y0 = tile_y * TH, x0 = tile_x * TW;
     const __bf16* pimg = pg + (long long)n_img * g.p_img_stride;
     const __bf16* qimg = qg + (long long)n_img * g.q_img_stride;
@@ -142,12 +139,12 @@ __device__ __forceinline__ void wg2_kstep(Wg2Frag<NT>& cur, Wg2Frag<NT>& nxt, co
 // (inline asm) between the MFMAs of step s and retired by counted lgkmcnt.
 template <int TWS, int TAP0, int NT>
 __device__ __forceinline__ void wg2_step(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
-                                         const int (&pdesc)[4], const int (&qdesc)[6], int wave, int next_tile,
+                                         const int (&pdesc)[4], const int (&qdesc)[6], int wave, bool has_next, int ntx, int nty, int nn,
                                          char* dma, uint32_t rd,
                                          const int (&pcol)[(1 << TWS) / 16][2], const int (&qcol)[(1 << TWS) / 16][2][3],
                                          f32x16 (&acc)[NT]) {
     constexpr int XSEG = (1 << TWS) / 16, PBYTES = 256 * 128;
-    if (next_tile >= 0) wg2_issue<TWS>(g, pg, qg, pdesc, qdesc, wave, next_tile, dma);
+    if (has_next) wg2_issue<TWS>(g, pg, qg, pdesc, qdesc, wave, ntx, nty, nn, dma);
     uint32_t pa[XSEG][2], qa[XSEG][2][3];
 #pragma unroll
     for (int xs = 0; xs < XSEG; ++xs)
@@ -175,11 +172,19 @@ __device__ __forceinline__ void wg2_run(const Wgrad2Args& g, const __bf16* pg, c
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    // coordinates of the NEXT tile, advanced on the scalar unit (a division per tile costs ~60 instructions)
+    int ntx, nty, nn;
+    {
+        int tt = t_begin;
+        ntx = tt % g.tiles_x; tt /= g.tiles_x;
+        nty = tt % g.tiles_y; nn = tt / g.tiles_y;
+    }
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int stage = (tile - t_begin) & 1;
+        if (++ntx == g.tiles_x) { ntx = 0; if (++nty == g.tiles_y) { nty = 0; ++nn; } }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                 // this wave's LDS-DMA has landed; barrier: tile complete, other stage free
-        wg2_step<TWS, TAP0, NT>(g, pg, qg, pdesc, qdesc, wave, tile + 1 < t_end ? tile + 1 : -1,
+        wg2_step<TWS, TAP0, NT>(g, pg, qg, pdesc, qdesc, wave, tile + 1 < t_end, ntx, nty, nn,
                                 smem + (stage ^ 1) * STAGE, lds_base + stage * STAGE, pcol, qcol, acc);
     }
     __syncthreads();                     // every wave is done reading the stages
@@ -259,7 +264,11 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args g) {
     const int t_begin = split * g.tiles_per_split;
     const int t_end = min(t_begin + g.tiles_per_split, g.ntiles);
 
-    if (t_begin < t_end) wg2_issue<TWS>(g, pg, qg, pdesc, qdesc, wave, t_begin, smem);
+    if (t_begin < t_end) {
+        int tt = t_begin;
+        const int tx = tt % g.tiles_x; tt /= g.tiles_x;
+        wg2_issue<TWS>(g, pg, qg, pdesc, qdesc, wave, tx, tt % g.tiles_y, tt / g.tiles_y, smem);
+    }
     // waves 0-3 take taps 0..4, waves 4-7 taps 5..8: every SIMD hosts one wave of each group
     if (kg == 0) wg2_run<TWS, 0, 5>(g, pg, qg, pdesc, qdesc, wave, t_begin, t_end, smem, pcol, qcol, wa * 32, wb * 32 + r, h);
     else         wg2_run<TWS, 5, 4>(g, pg, qg, pdesc, qdesc, wave, t_begin, t_end, smem, pcol, qcol, wa * 32, wb * 32 + r, h);
