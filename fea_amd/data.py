@@ -15,6 +15,7 @@ nothing under fea_amd/ imports the oracle).
 """
 from __future__ import annotations
 
+import collections
 import os
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
@@ -137,15 +138,31 @@ class FloorPlanPairs:
             order = torch.randperm(len(order), generator=torch.Generator().manual_seed(seed)).tolist()
         order = order[rank::world]
         S, dev = self.pre.size, self.pre.device
+        # bounded prefetch: at most two batches of decoded images are held (or being decoded) ahead
+        # of the GPU; each decoded pair is dropped as soon as it has been handed to the device
+        window = max(2 * batch_size, self.workers)
         with ThreadPoolExecutor(max_workers=self.workers) as pool:
-            futs = [(pool.submit(decode_rgb, self.items[i][0]), pool.submit(decode_grey, self.items[i][1])) for i in order]
-            for b0 in range(0, len(futs), batch_size):
-                chunk = futs[b0:b0 + batch_size]
-                x = torch.empty((len(chunk), 3, S, S), dtype=torch.float32, device=dev)
-                t = torch.zeros((len(chunk), self.num_classes, S, S), dtype=torch.uint8, device=dev)
-                for j, (fi, fm) in enumerate(chunk):
+            futs = collections.deque()
+            nxt = 0
+
+            def refill():
+                nonlocal nxt
+                while nxt < len(order) and len(futs) < window:
+                    i = order[nxt]
+                    futs.append((pool.submit(decode_rgb, self.items[i][0]), pool.submit(decode_grey, self.items[i][1])))
+                    nxt += 1
+
+            refill()
+            for b0 in range(0, len(order), batch_size):
+                nb = min(batch_size, len(order) - b0)
+                x = torch.empty((nb, 3, S, S), dtype=torch.float32, device=dev)
+                t = torch.zeros((nb, self.num_classes, S, S), dtype=torch.uint8, device=dev)
+                for j in range(nb):
+                    fi, fm = futs.popleft()
                     self.pre.image(fi.result(), out=x[j])
                     self.pre.mask(fm.result(), out=t[j, self.mask_channel])
+                    del fi, fm
+                    refill()
                 yield x, t
 
 

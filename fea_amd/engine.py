@@ -43,6 +43,20 @@ LEVEL = {"enc1": 0, "enc2": 1, "enc3": 2, "enc4": 3, "bottleneck": 4, "dec4": 3,
 BLOCKS = ["enc1", "enc2", "enc3", "enc4", "bottleneck", "dec4", "dec3", "dec2", "dec1"]
 
 
+def named_tensors(module, names) -> Dict[str, torch.Tensor]:
+    """Parameters (or buffers) of `module` by dotted name, through plain attribute access.  Works on
+    the replicas `nn.DataParallel` makes (train_direct.py:23-25), whose parameters are ordinary tensor
+    attributes (outputs of the broadcast), not registered `nn.Parameter`s: `named_parameters()` is
+    empty there."""
+    out = {}
+    for n in names:
+        obj = module
+        for part in n.split("."):
+            obj = getattr(obj, part)
+        out[n] = obj
+    return out
+
+
 def param_order(module) -> List[str]:
     """Parameter names in REVERSE-forward order: the order in which backward
     finishes their gradients (out, dec1, upconv1, dec2, ..., enc1).  The flat
@@ -101,11 +115,27 @@ class _Plan:
                 c = CH[blk]
                 self.coef[f"{blk}.{idx}"] = {k: es(c, dtype=torch.float32, device=dev)
                                              for k in ("scale", "shift", "mean", "invstd")}
+        self.nbytes = sum(t.numel() * t.element_size() for t in self._tensors())
         self.bwd_ready = False
         # > 0 while an autograd graph still needs this plan's activations for its backward
         # (the reference's pipeline calls the UNet once per floor before one backward,
         # models.py:190): such a plan is not reused by the next forward.
         self.leases = 0
+
+    def _tensors(self):
+        for k, v in vars(self).items():
+            if k in ("P", "x_in"):               # the caller's tensors, not the plan's
+                continue
+            if isinstance(v, torch.Tensor):
+                yield v
+            elif isinstance(v, dict):
+                for u in v.values():
+                    if isinstance(u, torch.Tensor):
+                        yield u
+                    elif isinstance(u, dict):
+                        yield from (w for w in u.values() if isinstance(w, torch.Tensor))
+            elif isinstance(v, list):
+                yield from (u for u in v if isinstance(u, torch.Tensor))
 
     def alloc_backward(self, eng: "UNetEngine"):
         if self.bwd_ready:
@@ -150,6 +180,7 @@ class _Plan:
         self.bncoef = es(1024 * 2, dtype=torch.float32, device=dev)
         self.head_part = es(L.call("fea_head_bwd_blocks", N, H, W) * eng.num_classes * 65, dtype=torch.float32, device=dev)
         self.bwd_ready = True
+        self.nbytes = sum(t.numel() * t.element_size() for t in self._tensors())
 
 
 class UNetEngine:
@@ -188,6 +219,9 @@ class UNetEngine:
         # that the HBM-bound BatchNorm-backward kernels of the following layers overlap them.
         self.overlap_wgrad = os.environ.get("FEA_AMD_WGRAD_STREAM", "1") != "0"
         self._wstream = None
+        self._P: Dict[str, torch.Tensor] = {}
+        self._B: Dict[str, torch.Tensor] = {}
+        self.backward_count = 0        # backward passes run so far (ClipAdamW checks that it steps on one backward's gradients)
         L.load()
 
     # ------------------------------------------------------------------ utils
@@ -195,8 +229,8 @@ class UNetEngine:
         return {"enc1": self.in_channels, "enc2": 64, "enc3": 128, "enc4": 256, "bottleneck": 512,
                 "dec4": 1024, "dec3": 512, "dec2": 256, "dec1": 128}[blk]
 
-    def _params(self) -> Dict[str, torch.nn.Parameter]:
-        return dict(self.m.named_parameters())
+    def _params(self) -> Dict[str, torch.Tensor]:
+        return named_tensors(self.m, self.m._param_names)
 
     def _bufs(self) -> Dict[str, torch.Tensor]:
         return dict(self.m.named_buffers())
@@ -210,7 +244,10 @@ class UNetEngine:
             self.folded.clear()
             self.flat_grad = None
 
-    MAX_LIVE_PLANS = 8        # forwards of one shape whose backward is still pending
+    # Forwards whose backward is still pending each hold a plan (saved activations; ~45 GB at batch
+    # 64 x 512^2 bf16 once its backward buffers exist): their total is bounded in BYTES, as a
+    # fraction of the device's memory, not by a count.
+    MAX_LEASED_FRACTION = 0.8
 
     def plan(self, N, H, W) -> _Plan:
         """A plan for this shape whose buffers nobody is waiting to run backward on."""
@@ -224,9 +261,16 @@ class UNetEngine:
         for p in pool:
             if p.leases == 0:
                 return p
-        if len(pool) >= self.MAX_LIVE_PLANS:
-            raise L.FeaError(f"{len(pool)} forward passes of shape {key} are waiting for their backward; "
-                             "run backward (or drop the graphs / use torch.no_grad()) before calling the model again")
+        if pool:
+            # every resident plan of this shape is leased: one more costs what they cost (with backward buffers)
+            held = sum(q.nbytes for v in self.plans.values() for q in v)
+            est = max(q.nbytes for q in pool)
+            total = torch.cuda.get_device_properties(self.device).total_memory
+            if held + est > self.MAX_LEASED_FRACTION * total:
+                raise L.FeaError(f"{len(pool)} forward passes of shape {key} are waiting for their backward and hold "
+                                 f"{held / 2**30:.1f} GiB; one more (~{est / 2**30:.1f} GiB) would exceed "
+                                 f"{self.MAX_LEASED_FRACTION:.0%} of the device's {total / 2**30:.0f} GiB: run backward (or drop "
+                                 "the graphs / use torch.no_grad()) before calling the model again")
         p = _Plan(self, N, H, W)
         pool.append(p)
         return p
@@ -237,6 +281,7 @@ class UNetEngine:
         params = self._params()
         order = param_order(self.m)
         assert set(order) == set(params), "parameter set differs from the reference's"
+        self._P = params
         off = 0
         for n in order:
             numel = params[n].numel()
@@ -263,7 +308,7 @@ class UNetEngine:
         self._gen += 1
 
     def _w_fwd(self, name: str):
-        p = self._params()[name + ".weight"]
+        p = self._P[name + ".weight"]
         if name == "enc1.0" and self.first_direct:
             ks = (9 * self.in_channels + 31) // 32
             return self._pack(name + "/f", p, ks * 64 * 32, "fea_pack_conv3x3_first", 64, self.in_channels)
@@ -278,7 +323,7 @@ class UNetEngine:
         (models.py:28-29 / 31-32 in eval mode).  Re-made when any of the six tensors changes."""
         blk, idx = name.rsplit(".", 1)
         bn = f"{blk}.{int(idx) + 1}"
-        P, B = self._params(), self._bufs()
+        P, B = self._P, self._B
         deps = [P[name + ".weight"], P[name + ".bias"], P[bn + ".weight"], P[bn + ".bias"],
                 B[bn + ".running_mean"], B[bn + ".running_var"]]
         ver = (self._gen, tuple(t._version for t in deps), tuple(t.data_ptr() for t in deps))
@@ -301,12 +346,12 @@ class UNetEngine:
         return ent[1], ent[2]
 
     def _w_dgrad(self, name: str):
-        p = self._params()[name + ".weight"]
+        p = self._P[name + ".weight"]
         co, ci = p.shape[0], p.shape[1]
         return self._pack(name + "/d", p, p.numel(), "fea_pack_conv3x3", co, ci, 1)
 
     def _w_up(self, name: str, bwd: int):
-        p = self._params()[name + ".weight"]
+        p = self._P[name + ".weight"]
         ci, co = p.shape[0], p.shape[1]
         return self._pack(name + ("/b" if bwd else "/f"), p, p.numel(), "fea_pack_upconv2x2", ci, co, bwd)
 
@@ -326,6 +371,8 @@ class UNetEngine:
         x = x.detach().contiguous().float()
         pl = self.plan(N, H, W)
         P, B = self._params(), self._bufs()
+        self._P, self._B = P, B
+        pl.P = P                                  # the tensors this forward used (a DataParallel replica's own copies)
         S = L.stream_ptr()
         code = self.code
         taps = self.debug_taps
@@ -468,7 +515,9 @@ class UNetEngine:
             torch.cuda.current_stream().wait_event(pl.bwd_packs_done)
             pl.bwd_packs_done = None
         N, H, W = pl.N, pl.H, pl.W
-        P = self._params()
+        P = pl.P
+        self._P = P
+        self.backward_count += 1
         S = L.stream_ptr()
         code = self.code
         g = self.grad_views

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .engine import UNetEngine
+from .engine import UNetEngine, named_tensors
 
 
 def _resolve_dtype(compute_dtype) -> torch.dtype:
@@ -60,26 +60,27 @@ class _UNetFunction(torch.autograd.Function):
     order the parameters were passed."""
 
     @staticmethod
-    def forward(ctx, module, x, *params):
-        eng = module._engine()
+    def forward(ctx, module, eng, x, *params):
+        eng.m = module                       # the module (or DataParallel replica) whose tensors this call uses
         logits = eng.forward(x, module.training)
-        ctx.module = module
+        ctx.eng = eng
         ctx.names = module._param_names
+        ctx.needs = [p.requires_grad for p in params]
         ctx.plan = eng._last[0]
         ctx.lease = _Lease(ctx.plan)
         # hand out a copy: the plan's logits buffer is overwritten by the next forward
+        # (the caller may keep the logits longer than the graph, e.g. for metrics)
         return logits.clone()
 
     @staticmethod
     def backward(ctx, dlogits):
-        module = ctx.module
-        grads = module._engine().backward(dlogits, plan=ctx.plan)
+        grads = ctx.eng.backward(dlogits, plan=ctx.plan)
         # copies: the flat gradient buffer is rewritten by the next backward (a second
-        # forward of the same graph, models.py:190), autograd accumulates what we return
-        out = tuple(grads[n].clone() if p.requires_grad else None
-                    for n, p in zip(ctx.names, module.parameters()))
+        # forward of the same graph, models.py:190); autograd accumulates what we return and
+        # may keep it as .grad, so it must not alias the engine's buffer
+        out = tuple(grads[n].clone() if need else None for n, need in zip(ctx.names, ctx.needs))
         ctx.lease.release()
-        return (None, None) + out
+        return (None, None, None) + out
 
 
 class FloorPlanSegmentationModel(nn.Module):
@@ -111,7 +112,11 @@ class FloorPlanSegmentationModel(nn.Module):
         self.num_classes = num_classes
         self.compute_dtype = _resolve_dtype(compute_dtype)
         self._param_names = [n for n, _ in self.named_parameters()]
-        self.__dict__["_eng"] = None      # not a sub-module / not in state_dict
+        # engines by (device, compute dtype).  Not sub-modules, not in state_dict.  The dict OBJECT is
+        # shared with the replicas nn.DataParallel makes (their __dict__ is a shallow copy), so the
+        # replica on device k finds device k's engine again on the next step; an engine resolves
+        # its parameters from the module that calls it (see engine.named_tensors).
+        self.__dict__["_engs"] = {}
 
     def _conv_block(self, in_c, out_c):
         return nn.Sequential(
@@ -124,18 +129,26 @@ class FloorPlanSegmentationModel(nn.Module):
         )
 
     # -- engine -----------------------------------------------------------
-    def _engine(self) -> UNetEngine:
-        eng = self.__dict__.get("_eng")
-        if eng is None or eng.dtype != self.compute_dtype:
+    def _engine(self, device=None) -> UNetEngine:
+        """The engine (plans, packed weights, gradient buffer) of `device` (default: where the
+        parameters live).  One per device: under nn.DataParallel (train_direct.py:23-25) every
+        replica thread works with its own device's engine."""
+        if device is None:
+            device = self.out.weight.device
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        key = (str(device), self.compute_dtype)
+        eng = self._engs.get(key)
+        if eng is None:
             eng = UNetEngine(self, self.compute_dtype)
-            self.__dict__["_eng"] = eng
+            self._engs[key] = eng
         return eng
 
     def train(self, mode: bool = True):
         # leaving / entering eval mode: packed weights may be stale (fused
         # optimizers do not bump Parameter._version)
-        eng = self.__dict__.get("_eng")
-        if eng is not None:
+        for eng in self.__dict__.get("_engs", {}).values():
             eng.invalidate()
         return super().train(mode)
 
@@ -147,15 +160,20 @@ class FloorPlanSegmentationModel(nn.Module):
         if not x.is_cuda:
             raise L.FeaError("fea_amd.FloorPlanSegmentationModel runs on a ROCm device only; "
                              "there is no CPU fallback (use the reference module for CPU execution)")
-        for p in self.parameters():
-            if p.dtype != torch.float32:
-                raise L.FeaError("parameters must stay fp32 (use compute_dtype='bf16' for bf16 arithmetic)")
-            break
+        # by attribute, not self.parameters(): a DataParallel replica has none registered
+        tens = named_tensors(self, self._param_names)
+        w = tens["out.weight"]
+        if w.dtype != torch.float32:
+            raise L.FeaError("parameters must stay fp32 (use compute_dtype='bf16' for bf16 arithmetic)")
+        if w.device != x.device:
+            raise L.FeaError(f"input on {x.device} but parameters on {w.device}")
         in_dtype = x.dtype
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            logits = _UNetFunction.apply(self, x, *self.parameters())
+        eng = self._engine(x.device)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tens.values()):
+            logits = _UNetFunction.apply(self, eng, x, *tens.values())
         else:
-            logits = self._engine().forward(x, self.training).clone()
+            eng.m = self
+            logits = eng.forward(x, self.training).clone()
         return logits if in_dtype == torch.float32 else logits.to(in_dtype)
 
     # -- checkpoints --------------------------------------------------------

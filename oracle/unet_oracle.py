@@ -170,6 +170,8 @@ def _conv_block(x, p, b, name, training, new_bufs, taps=None, forced=None):
             new_bufs[bn + ".num_batches_tracked"] = b[bn + ".num_batches_tracked"] + 1
         else:
             new_bufs[bn + ".num_batches_tracked"] = b[bn + ".num_batches_tracked"]
+        if taps is not None:
+            taps[f"{name}.{idx}.bn"] = x             # pre-activation (input of the ReLU)
         if forced is not None:
             # kinks pinned: the ReLU mask comes from the implementation under
             # test, so both sides differentiate the same smooth branch
@@ -185,6 +187,39 @@ def _upconv(x, w, bias):
     """nn.ConvTranspose2d(ci, co, 2, stride=2) (models.py:15-21):
     y[n,co,2i+a,2j+b] = bias[co] + sum_ci x[n,ci,i,j] * w[ci,co,a,b]."""
     return F.conv_transpose2d(x, w, bias, stride=2)
+
+
+def kink_disagreements(taps_hip, taps_free, rel_band=1e-5):
+    """How far the kink decisions of an implementation under test (`taps_hip`: its activated outputs) are from this
+    oracle's own (`taps_free`: taps of a free forward(), with `.bn` pre-activations).  Pinning the kinks (forced_from_taps)
+    is only legitimate where the two disagree inside a rounding band: returns, per layer,
+      relu:  (number of mask disagreements, how many of them have |pre-activation| >= rel_band * RMS(pre-activation), numel,
+              worst |pre-activation| / RMS among the disagreements)
+      pool:  (number of arg-max disagreements, how many of them have a window gap (max - runner-up) >= rel_band * RMS, windows,
+              worst gap / RMS among the disagreements)
+    A kernel that mis-masks pixels away from the kink shows up in the second and fourth figures."""
+    out = {}
+    for k, act in taps_hip.items():
+        if not k.endswith(".act"):
+            continue
+        pre = taps_free[k[:-4] + ".bn"].detach()
+        rms = pre.pow(2).mean().sqrt().item()
+        dis = (act > 0) != (pre > 0)
+        worst = (pre.abs()[dis].max().item() / rms) if dis.any() else 0.0
+        out[k[:-4] + ".relu"] = (int(dis.sum()), int((dis & (pre.abs() >= rel_band * rms)).sum()), pre.numel(), worst)
+    for blk in ("enc1", "enc2", "enc3", "enc4"):
+        a_free = taps_free[f"{blk}.3.act"].detach()
+        _, idx_hip = F.max_pool2d(taps_hip[f"{blk}.3.act"].float(), 2, return_indices=True)
+        _, idx_free = F.max_pool2d(a_free, 2, return_indices=True)
+        n, c, h, w = a_free.shape
+        win = a_free.view(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
+        top2 = win.topk(2, dim=-1).values
+        gap = top2[..., 0] - top2[..., 1]
+        rms = a_free.pow(2).mean().sqrt().item()
+        dis = idx_hip != idx_free
+        worst = (gap[dis].max().item() / rms) if dis.any() else 0.0
+        out[f"{blk}.pool"] = (int(dis.sum()), int((dis & (gap >= rel_band * rms)).sum()), dis.numel(), worst)
+    return out
 
 
 def forced_from_taps(taps):
@@ -269,9 +304,9 @@ def iou_from_counts(inter, union):
 # --------------------------------------------------------------------------
 # A9/A10: backward via autograd on the restated forward; clip + AdamW by hand
 # --------------------------------------------------------------------------
-def loss_and_grads(params, bufs, x, target, training=True):
+def loss_and_grads(params, bufs, x, target, training=True, forced=None):
     p = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in params.items())
-    logits, nb = forward(p, bufs, x, training)
+    logits, nb = forward(p, bufs, x, training, forced=forced)
     loss = bce_dice_loss(logits, target)
     grads = torch.autograd.grad(loss, list(p.values()))
     return loss.detach(), logits.detach(), OrderedDict(zip(p.keys(), grads)), nb

@@ -64,6 +64,8 @@ SHAPES_3X3 = [  # N, H, W, Cin, Cout
     (1, 24, 40, 64, 128),       # partial tiles in both directions
     (1, 8, 8, 192, 64),         # tile larger than the image
     (3, 16, 64, 64, 192),       # BN = 64 path with several cout tiles
+    (1, 8, 32, 1024, 128),      # deep K (16 chunks) on the 8x32-tile, 128-column kernel (bottleneck / dec4.0 shapes)
+    (2, 16, 32, 512, 1024),     # the same with 8 column tiles and two tile rows
 ]
 
 
@@ -405,9 +407,8 @@ def test_bn_relu_pool_forward_backward(dt, shape):
     L.call("fea_reduce_partials", part, nblk, c, 0, dbias, S())
     torch.cuda.synchronize()
     assert rel_l2(dgamma.cpu(), gr.grad) < 2e-4 and rel_l2(dbeta.cpu(), br.grad) < 2e-4
-    if pool:
-        # only windows whose maximum is unique after rounding are comparable
-        pass
+    # (gaussian inputs: pool windows have no exact ties; exact ties are covered by
+    # test_maxpool_backward_exact_ties_go_to_the_first_maximum)
     check(from_nhwc(dy, c), yr.grad, dt, "bn+relu(+pool) backward", scale=3.0)
     # conv-bias gradient under BN is rounding noise around 0
     assert dbias.abs().max().item() < 1e-2 * (yr.grad.abs().sum((0, 2, 3)).max().item() + 1e-6)
@@ -478,6 +479,39 @@ def test_loss_mask_iou(shape):
     out = torch.empty(1000, dtype=torch.uint8, device=DEV)
     L.call("fea_binarise", grey.to(DEV), out, 1000, S())
     assert torch.equal(out.cpu(), O.binarise_mask(grey))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_maxpool_backward_exact_ties_go_to_the_first_maximum(dt):
+    """MaxPool2d(2) backward on windows with EXACT non-zero ties (models.py:24): the gradient goes to the first maximum
+    in row-major window order, as torch's CPU kernel does (SURVEY 8(a) A4).  Small integers are exact in bf16 and fp32;
+    with scale 1, shift 0, mean 0, invstd 1 and zero coefficients, fea_bn_relu_bwd_apply reduces to ReLU-mask x pool
+    routing, so the comparison is bit-exact."""
+    code = L.dt_code(dt)
+    n, c, h, w = 2, 64, 16, 24
+    g = torch.Generator().manual_seed(23)
+    y = torch.randint(-1, 3, (n, c, h, w), generator=g).float()           # {-1,0,1,2}: most windows tie
+    y[0, :, 0:2, 0:2] = 2.0                                                # four-way tie
+    y[0, :, 0:2, 2:4] = torch.tensor([[1.0, 2.0], [2.0, 0.0]])             # tie between positions 1 and 2
+    y[0, :, 2:4, 0:2] = torch.tensor([[0.0, 1.0], [0.0, 1.0]])             # tie between positions 1 and 3
+    dp = torch.randint(1, 8, (n, c, h // 2, w // 2), generator=g).float()
+    yr = y.clone().requires_grad_(True)
+    F.max_pool2d(torch.relu(yr), 2).backward(dp)
+    ties = (F.max_pool2d(torch.relu(y), 2).repeat_interleave(2, 2).repeat_interleave(2, 3) == torch.relu(y)) & (y > 0)
+    assert (ties.view(n, c, h // 2, 2, w // 2, 2).sum((3, 5)) > 1).float().mean() > 0.3, "test vector has too few ties"
+    one, zero = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+    coef = torch.zeros(c, 2, device=DEV)
+    nblk = L.call("fea_bn_bwd_blocks", n, h, w, c)
+    part = torch.empty(nblk, c, 2, device=DEV)
+    dy = torch.full((n, h, w, c), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_bn_relu_bwd_apply", None, 0, to_nhwc(dp, dt), to_nhwc(y, dt), one, zero, zero, one, coef, dy, part,
+           n, h, w, c, code, S())
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(dy, c), yr.grad), "pool gradient not routed to the first maximum"
+    # the reduce pass sees the same routing: sum g per channel
+    L.call("fea_bn_relu_bwd_reduce", None, 0, to_nhwc(dp, dt), to_nhwc(y, dt), one, zero, zero, one, part, n, h, w, c, code, S())
+    torch.cuda.synchronize()
+    assert torch.equal(part[..., 0].double().sum(0).cpu(), yr.grad.double().sum((0, 2, 3)))
 
 
 def test_bad_arguments_are_rejected():

@@ -25,6 +25,11 @@ from tests.test_oracle_golden import case_inputs
 
 pytestmark = pytest.mark.gpu
 GOLD = load_golden()
+# fp32 path: a ReLU / pool decision may differ from the oracle's only where the oracle's pre-activation (or pool-window
+# gap) is below this fraction of the layer's RMS -- i.e. inside accumulated fp32 rounding.  Observed worst case:
+# <= 7e-6 x RMS on the small shapes, 1.3e-5 at bottleneck.3 of the batch-16 256x256 case (ten layers deep);
+# north_star's forward tolerance is 1e-4.
+KINK_BAND = 5e-5
 
 
 def cancelled(k):
@@ -37,6 +42,20 @@ def make(seed, dt, **kw):
     m = fea_amd.FloorPlanSegmentationModel(compute_dtype=dt, **kw).cuda()
     params, bufs = O.split_state({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
     return m, params, bufs
+
+
+def assert_kinks_within_rounding(taps, taps_free, rel_band=KINK_BAND, max_frac=1e-4):
+    """The pinning of ReLU masks / pool arg-max to the HIP run's decisions (oracle `forced=`) is bounded: wherever the
+    HIP decision differs from the oracle's own, the oracle's pre-activation (or its pool-window gap) must lie inside a
+    rounding band of `rel_band` x the layer's RMS, and such disagreements must be rarer than `max_frac` of the
+    elements.  A kernel that mis-masked pixels away from a kink would fail here instead of being forgiven by its own
+    mask."""
+    worst_all = 0.0
+    for layer, (ndis, noutside, numel, worst) in O.kink_disagreements(taps, taps_free, rel_band).items():
+        assert noutside == 0, f"{layer}: {noutside} kink decisions differ outside the rounding band ({ndis} differ in all, worst at {worst:.2e} x RMS)"
+        assert ndis <= max(1, max_frac * numel), f"{layer}: {ndis} of {numel} kink decisions differ"
+        worst_all = max(worst_all, worst)
+    print(f"kink decisions: worst disagreement at {worst_all:.2e} x layer RMS (band {rel_band:.0e})")
 
 
 def run_hip(m, x, dl):
@@ -61,8 +80,11 @@ def test_fp32_forward_backward_buffers(shape):
     lg, taps = run_hip(m, x, dl)
     forced = O.forced_from_taps(taps)
     lo, go, nb = O.grads_from_dlogits(params, bufs, x, dl, forced=forced)
-    lo_free, _ = O.forward(params, bufs, x, True)
+    taps_free = {}
+    with torch.no_grad():
+        lo_free, _ = O.forward(params, bufs, x, True, taps=taps_free)
     assert rel_l2(lg, lo_free) < 1e-4 and max_rel(lg, lo_free) < 1e-4
+    assert_kinks_within_rounding(taps, taps_free)
     for k, p in m.named_parameters():
         if cancelled(k):
             # mathematically zero (BN cancels the conv bias): both sides are rounding noise
@@ -112,9 +134,10 @@ def test_bf16_forward_backward(shape):
             assert rel_l2(b, nb[k]) < 3e-2, k
 
 
-@pytest.mark.parametrize("name", ["train_32", "train_c1", "plan_64"])
+@pytest.mark.parametrize("name", ["train_32", "train_64", "train_c1", "plan_64"])
 def test_against_reference_golden_digests(name):
-    """HIP fp32 path against digests of the REFERENCE module's own outputs."""
+    """HIP fp32 path against digests of the REFERENCE module's own outputs: logits, loss, gradients, BatchNorm
+    buffers, and the parameters after clip_grad_norm_(1.0) + AdamW (train_direct.py:105-106)."""
     case = GOLD[name]
     torch.manual_seed(case["seed"])
     m = fea_amd.FloorPlanSegmentationModel(in_channels=case["in_channels"], num_classes=case["num_classes"],
@@ -135,6 +158,40 @@ def test_against_reference_golden_digests(name):
             assert digest_err(rec["grads"][k], p.grad.cpu()) < 5e-2, k
     for k, b in m.named_buffers():
         assert digest_err(rec["buffers"][k], b.float().cpu()) < 1e-4, k
+    # optimizer step: our ClipAdamW on the autograd-accumulated p.grad (copied into the flat buffer)
+    from fea_amd.optim import ClipAdamW
+    opt = ClipAdamW(list(m.named_parameters()), m._engine(), lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0)
+    norm = opt.step()
+    assert abs(float(norm) - rec["grad_norm"]) <= (2e-4 if case["strict"] else 2e-2) * rec["grad_norm"]
+    lr = 1e-4
+    for k, p in m.named_parameters():
+        gd = rec["params_after"][k]
+        ref = torch.tensor(gd["samples"], dtype=torch.float64)
+        got = torch.tensor(O.digest(p.detach().cpu(), len(gd["samples"]))["samples"], dtype=torch.float64)
+        err = (ref - got).abs().max().item()
+        # an Adam update is lr * g / (|g| + eps)-like: sign-like for noise gradients (BN-cancelled biases) and after
+        # a kink flip, so the bound is absolute, as in tests/test_oracle_golden.py
+        if cancelled(k) or not case["strict"]:
+            assert err <= 2.1 * lr, (k, err)
+        else:
+            assert err <= 1e-4 * ref.abs().max().item() + 0.5 * lr, (k, err)
+
+
+def test_dlogits_backward_matches_reference_digests():
+    """Backward of the UNet alone for a random upstream gradient (golden `dlogits_32`, made by the reference)."""
+    case = GOLD["dlogits_32"]
+    torch.manual_seed(case["seed"])
+    m = fea_amd.FloorPlanSegmentationModel(compute_dtype="fp32").cuda().train()
+    g = torch.Generator().manual_seed(case["seed"] + 7)
+    x = torch.randn(case["n"], 3, case["h"], case["w"], generator=g)
+    dl = torch.randn(case["n"], 6, case["h"], case["w"], generator=g) / (case["n"] * case["h"] * case["w"])
+    logits = m(x.cuda())
+    logits.backward(dl.cuda())
+    torch.cuda.synchronize()
+    assert digest_err(case["logits"], logits.detach().cpu()) < 1e-4
+    for k, p in m.named_parameters():
+        if not cancelled(k):
+            assert digest_err(case["grads"][k], p.grad.cpu()) < 5e-2, k       # kinks unpinned (see above)
 
 
 def test_config1_eval_forward_matches_reference():
@@ -413,3 +470,218 @@ def test_hip_optimizer_matches_torch_adamw_and_shares_checkpoints():
             ob.load_state_dict(sa)
             oa.load_state_dict(sb)
     assert oa._t == 4 and float(ob.state[next(iter(mb.parameters()))]["step"]) == 4
+
+
+def test_config2_train_step_fp32_batch16_256_matches_oracle():
+    """BASELINE configs[1] at full size: one training step (forward, BCE+Dice, backward) at batch 16, 256x256, fp32.
+    Logits and loss within 1e-4 of the free-running oracle; every gradient within 1e-4 with the kinks pinned, the
+    pinning itself bounded by assert_kinks_within_rounding.  (One oracle step takes ~15-25 s on the box's cores.)"""
+    m, params, bufs = make(20, "fp32")
+    m.train()
+    x, tgt = O.synthetic_batch(16, 256, 256, seed=77)
+    x = x + 0.1 * torch.randn(x.shape, generator=torch.Generator().manual_seed(4))
+    taps = {}
+    m._engine().debug_taps = taps
+    m.zero_grad()
+    logits = m(x.cuda())
+    m._engine().debug_taps = None
+    loss = Fn.bce_dice_loss(logits, tgt.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    taps = {k: v.cpu() for k, v in taps.items()}
+    taps_free = {}
+    with torch.no_grad():
+        lo_free, _ = O.forward(params, bufs, x, True, taps=taps_free)
+        loss_free = O.bce_dice_loss(lo_free, tgt)
+    assert rel_l2(logits.detach(), lo_free) < 1e-4 and max_rel(logits.detach(), lo_free) < 1e-4
+    assert abs(loss.item() - loss_free.item()) < 1e-4 * abs(loss_free.item())
+    assert_kinks_within_rounding(taps, taps_free)
+    del taps_free
+    lo, _, go, nb = O.loss_and_grads(params, bufs, x, tgt, training=True, forced=O.forced_from_taps(taps))
+    for k, p in m.named_parameters():
+        if cancelled(k):
+            scale = go[k.replace(".bias", ".weight")].abs().max().item()
+            assert p.grad.abs().max().item() < 1e-3 * scale + 1e-7, k
+        elif k.startswith("upconv") and k.endswith(".bias"):
+            # NEARLY cancelled (see test_bf16_forward_backward): a sum over 1 M pixels of which only the border
+            # survives dec_K.0's BatchNorm; the fp32 summation noise of both sides is measured against the same
+            # layer's weight gradient (the small fp32 shapes above hold 1e-4 on the bias itself)
+            assert (p.grad.cpu() - go[k]).norm().item() < 1e-4 * go[k.replace(".bias", ".weight")].norm().item(), k
+        else:
+            assert rel_l2(p.grad, go[k]) < 1e-4, (k, rel_l2(p.grad, go[k]))
+    for k, b in m.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            assert rel_l2(b, nb[k]) < 1e-4, k
+
+
+def test_bf16_well_conditioned_batch_8x128x128():
+    """bf16 storage path with BatchNorm statistics over >= 512 samples per channel at every level (8 x 128 x 128 ->
+    8 x 8 x 8 at the bottleneck): stated bounds, kinks pinned -- logits 2e-2 L2-relative, gradients 8e-2 worst layer /
+    3e-2 median layer, BatchNorm running statistics 1e-2."""
+    m, params, bufs = make(13, "bf16")
+    m.train()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(8, 3, 128, 128, generator=g)
+    dl = torch.randn(8, 6, 128, 128, generator=g) / (8 * 128 * 128)
+    lg, taps = run_hip(m, x, dl)
+    lo, go, nb = O.grads_from_dlogits(params, bufs, x, dl, forced=O.forced_from_taps(taps))
+    assert rel_l2(lg, lo) < 2e-2, rel_l2(lg, lo)
+    near = lambda k: k.startswith("upconv") and k.endswith(".bias")
+    errs = sorted((rel_l2(p.grad, go[k]), k) for k, p in m.named_parameters() if not cancelled(k) and not near(k))
+    assert errs[-1][0] < 8e-2 and errs[len(errs) // 2][0] < 3e-2, (errs[-1], errs[len(errs) // 2])
+    for k, b in m.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            assert rel_l2(b, nb[k]) < 1e-2, (k, rel_l2(b, nb[k]))
+
+
+def test_bf16_training_steps_track_the_fp32_oracle():
+    """The path bench.py times (bf16 storage, fp32 accumulate, UNetTrainer.step) against the fp32 oracle over five
+    optimizer steps on one batch: loss within 2 % at every step and decreasing on both sides; gradient norm within
+    10 %; thresholded masks of the final eval-mode logits agree on >= 98 % of the pixels (disagreements sit at
+    logits near 0: bf16 rounding of ~1e-2 relative on |logit| < 0.05)."""
+    m, params, bufs = make(14, "bf16")
+    tr = UNetTrainer(m, dict(learning_rate=1e-3))
+    x, tgt = O.synthetic_batch(4, 64, 64, seed=31)
+    x = x + 0.1 * torch.randn(x.shape, generator=torch.Generator().manual_seed(9))
+    state = {}
+    hip_losses, ref_losses = [], []
+    for step in range(5):
+        loss = tr.step(x.cuda(), tgt.cuda())
+        lo, _, grads, nb = O.loss_and_grads(params, bufs, x, tgt, training=True)
+        clipped, norm = O.clip_grad_norm(grads, 1.0)
+        params = O.adamw_step(params, clipped, state, lr=1e-3)
+        bufs = nb
+        hip_losses.append(loss.item())
+        ref_losses.append(lo.item())
+        assert abs(loss.item() - lo.item()) < 2e-2 * abs(lo.item()), (step, loss.item(), lo.item())
+        assert abs(tr.last_grad_norm.item() - norm.item()) < 1e-1 * norm.item(), (step, tr.last_grad_norm.item(), norm.item())
+    assert hip_losses[-1] < hip_losses[0] and ref_losses[-1] < ref_losses[0]
+    m.eval()
+    with torch.no_grad():
+        le = m(x.cuda()).cpu()
+    lo_e, _ = O.forward(params, bufs, x, False)
+    agree = ((le > 0) == (lo_e > 0)).float().mean().item()
+    assert agree >= 0.98, agree
+    flips = (le > 0) != (lo_e > 0)
+    assert lo_e[flips].abs().max().item() < 0.25 if flips.any() else True
+
+
+def test_config5_tiled_2048_inference_and_iou():
+    """BASELINE configs[4] at real size: one 2048 x 2048 image through TiledSegmenter (bf16, folded BatchNorm).
+    Property check (the oracle would need minutes): 1024-px cores (4 windows of 1216^2) and 512-px cores (16 windows
+    of 704^2) compute every logit from the same receptive field, so they agree to accumulation-order rounding of the
+    bf16 path; masks differ only where |logit| is inside that rounding; IoU counts are exact for the stitched logits."""
+    from fea_amd.inference import TiledSegmenter
+    torch.manual_seed(6)
+    m = fea_amd.FloorPlanSegmentationModel(compute_dtype="bf16").cuda()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.uniform_(-0.2, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+    m.eval()
+    x, tgt = O.synthetic_batch(1, 2048, 2048, seed=12)
+    x = (x + 0.05 * torch.randn(x.shape, generator=torch.Generator().manual_seed(2))).cuda()
+    tgt = tgt.cuda()
+    a = TiledSegmenter(m, core=1024, window_batch=2).logits(x)
+    b = TiledSegmenter(m, core=512, window_batch=8).logits(x)
+    assert a.shape == (1, 6, 2048, 2048) and torch.isfinite(a).all()
+    assert rel_l2(a, b) < 2e-2, rel_l2(a, b)
+    mask, inter, union = TiledSegmenter(m, core=1024, window_batch=2).segment(x, tgt)
+    pm, pi, pu = O.mask_iou_counts(a.cpu(), tgt.cpu())
+    assert torch.equal(mask.cpu(), pm) and torch.equal(inter.cpu(), pi) and torch.equal(union.cpu(), pu)
+    flips = (a > 0) != (b > 0)
+    if flips.any():
+        assert a[flips].abs().max().item() < 2e-2 * a.abs().max().item()
+
+
+def test_distributed_trainer_world1_nccl_is_bit_identical():
+    """The real multi-rank step (UNetTrainer(distributed=True): RCCL all-reduce of gradient buckets on a side stream,
+    triggered from inside backward) run with world size 1 must reproduce the non-distributed step bit for bit."""
+    import os
+    import socket
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        x, tgt = O.synthetic_batch(4, 64, 64, seed=41)
+        x, tgt = x.cuda(), tgt.cuda()
+        res = []
+        for distributed in (False, True):
+            torch.manual_seed(15)
+            m = fea_amd.FloorPlanSegmentationModel(compute_dtype="bf16").cuda()
+            tr = UNetTrainer(m, distributed=distributed, bucket_mb=16.0)
+            losses = [tr.step(x, tgt).clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            if distributed:
+                assert tr.buckets is not None and len(tr.buckets.buckets) >= 3
+            res.append((losses, [p.detach().clone() for p in m.parameters()]))
+        for la, lb in zip(res[0][0], res[1][0]):
+            assert torch.equal(la, lb)
+        for pa, pb in zip(res[0][1], res[1][1]):
+            assert torch.equal(pa, pb)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_replica_uses_its_own_tensors_and_engine():
+    """The reference's multi-GPU mode is nn.DataParallel (train_direct.py:23-25): replicas are shallow copies whose
+    parameters are plain tensor attributes produced by a broadcast.  A replica must compute with ITS tensors, and the
+    gradients must flow back through the broadcast to the original parameters.  (One GPU here: one replica on cuda:0.)"""
+    from torch.nn.parallel import replicate
+    m, params, bufs = make(16, "fp32")
+    m.train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 32, 32, generator=g)
+    dl = torch.randn(2, 6, 32, 32, generator=g) / 2048
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    lg_ref, _ = run_hip(m, x, dl)
+    want = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.load_state_dict(sd0)                                   # undo the BatchNorm buffer update
+    (rep,) = replicate(m, [torch.device("cuda", 0)])
+    assert getattr(rep, "_is_replica", False) and len(list(rep.parameters())) == 0
+    m.zero_grad()
+    out = rep(x.cuda())
+    assert out.requires_grad
+    out.backward(dl.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(out.detach().cpu(), lg_ref)
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.equal(p.grad, want[k]), k
+    # through the wrapper itself (single device: DataParallel calls the module directly)
+    dp = torch.nn.DataParallel(m)
+    m.zero_grad()
+    dp(x.cuda()).backward(dl.cuda())
+    assert m.out.weight.grad is not None
+
+
+def test_clip_adamw_steps_on_autograd_accumulated_gradients():
+    """ClipAdamW as a drop-in torch optimizer behind the module: two forwards (two floors, models.py:190), ONE backward
+    through both; p.grad is autograd's accumulation, not the engine's buffer, and must be what the step uses.  Frozen
+    parameters are left alone."""
+    from fea_amd.optim import ClipAdamW
+    torch.manual_seed(17)
+    ma = fea_amd.FloorPlanSegmentationModel(compute_dtype="fp32").cuda().train()
+    mb = fea_amd.FloorPlanSegmentationModel(compute_dtype="fp32").cuda().train()
+    mb.load_state_dict(ma.state_dict())
+    for mm in (ma, mb):
+        mm.enc1[0].weight.requires_grad_(False)
+    oa = ClipAdamW(list(ma.named_parameters()), ma._engine(), lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0)
+    ob = torch.optim.AdamW(mb.parameters(), lr=1e-3, weight_decay=1e-2)
+    g = torch.Generator().manual_seed(2)
+    floors = [torch.randn(2, 3, 32, 32, generator=g).cuda() for _ in range(2)]
+    frozen = ma.enc1[0].weight.detach().clone()
+    for mm, opt in ((ma, oa), (mb, ob)):
+        opt.zero_grad()
+        sum(mm(f).square().mean() for f in floors).backward()
+        if opt is ob:
+            torch.nn.utils.clip_grad_norm_(mb.parameters(), 1.0)
+        opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(ma.enc1[0].weight, frozen)
+    for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+        assert torch.allclose(pa, pb, rtol=2e-6, atol=2e-7), (k, (pa - pb).abs().max().item())
