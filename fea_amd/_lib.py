@@ -62,6 +62,7 @@ SIGNATURES = {
     "fea_head_bwd_finalize": (I, [P, I, P, P, I, I, P]),
     "fea_bce_dice_sums": (I, [P, P, P, P, I, I, L, P]),
     "fea_loss_blocks": (I, [I, I, L]),
+    "fea_bce_dice_sums_static": (I, [P, P, P, I, I, L, P]),
     "fea_bce_dice_grad": (I, [P, P, P, P, P, F, I, I, L, P]),
     "fea_mask_iou": (I, [P, P, P, P, P, I, I, L, P]),
     "fea_binarise": (I, [P, P, L, P]),

@@ -1,6 +1,7 @@
 // 1x1 classification head (models.py:23,46) and the build-defined segmentation
 // loss / mask / IoU.  All bandwidth-bound.
 #include "common.h"
+#include <mutex>
 
 // 8 lanes cooperate on one pixel: lane `sub` owns input channels 8*sub..8*sub+7.
 template <typename T> __device__ __forceinline__ void load8(const T* p, float* f);
@@ -422,6 +423,50 @@ extern "C" int fea_bce_dice_sums(const float* logits, const uint8_t* target, dou
     hipLaunchKernelGGL(bce_dice_sums_finalize_kernel, dim3(Ccls), dim3(256), 0, s, part, sums, N, Ccls, chunks);
     FEA_LAUNCH_CHECK();
     return FEA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// fea_bce_dice_sums for callers that cannot allocate (HIP graph capture, tight serving / evaluation
+// loops, harnesses that forbid hipMalloc): the per-block partial sums live in a fixed device array of
+// this code object instead of a caller workspace.  Every GPU holds its own copy of the array at its
+// own address; the address is looked up once per device (first call on that device, with the device
+// current) and kept.  Host code never uses the array's NAME as a pointer: it is a host-side stand-in.
+#define FEA_STATIC_LOSS_BLOCKS 65536                         // 1 MiB of fp32 partials per GPU, held until the process ends
+static __device__ __align__(256) float scratch[FEA_STATIC_LOSS_BLOCKS * 4];
+
+#define FEA_MAX_DEVICES 64
+static float* g_scratch_ptr[FEA_MAX_DEVICES];                // per device, resolved lazily
+static std::mutex g_scratch_mu;
+
+static int static_scratch(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    FEA_CHECK(e == hipSuccess && dev >= 0 && dev < FEA_MAX_DEVICES, FEA_E_LAUNCH, "fea_bce_dice_sums_static: hipGetDevice: %s (device %d)",
+              hipGetErrorString(e), dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        FEA_CHECK(e == hipSuccess && p, FEA_E_LAUNCH, "fea_bce_dice_sums_static: hipGetSymbolAddress on device %d: %s", dev, hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return FEA_OK;
+}
+
+extern "C" int fea_bce_dice_sums_static(const float* logits, const uint8_t* target, double* sums,
+                                        int N, int Ccls, long long HW, void* stream) {
+    FEA_CHECK(logits && target && sums && N > 0 && Ccls > 0 && HW > 0, FEA_E_BADARG, "fea_bce_dice_sums_static: bad args");
+    int chunks; long long cl; loss_plan(HW, chunks, cl);
+    const long long nblk = (long long)N * Ccls * chunks;
+    FEA_CHECK(nblk <= FEA_STATIC_LOSS_BLOCKS, FEA_E_WORKSPACE,
+              "fea_bce_dice_sums_static: N*classes*ceil(HW/8192) = %lld partial-sum blocks exceed the built-in scratch of %d "
+              "(use fea_bce_dice_sums with a caller workspace)", nblk, FEA_STATIC_LOSS_BLOCKS);
+    float* part = nullptr;
+    int rc = static_scratch(&part);
+    if (rc) return rc;
+    // every block [0, nblk) of the scratch is overwritten before the finalize kernel reads it: nothing to clear
+    return fea_bce_dice_sums(logits, target, sums, part, N, Ccls, HW, stream);
 }
 
 extern "C" int fea_bce_dice_grad(const float* logits, const uint8_t* target, const double* sums, float* loss, float* dlogits,

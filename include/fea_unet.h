@@ -217,6 +217,16 @@ int fea_head_bwd_finalize(const float* part, int nblk, float* dW, float* db, int
 int fea_bce_dice_sums(const float* logits, const uint8_t* target, double* sums, float* part,
                       int N, int Ccls, long long HW, void* stream);
 int fea_loss_blocks(int N, int Ccls, long long HW);
+/* fea_bce_dice_sums WITHOUT a caller workspace, for callers that cannot allocate (code under HIP
+ * graph capture, tight evaluation / serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  The per-block partial sums go to a fixed 1 MiB device array inside
+ * the library (one copy per GPU, held until the process ends); the call allocates nothing, frees
+ * nothing and gives bit-identical `sums` to fea_bce_dice_sums.  Limit: fea_loss_blocks(N, Ccls, HW)
+ * <= 65536, else FEA_E_WORKSPACE (batch 64 x 6 classes x 512^2 needs 12288).  The first call on a
+ * device looks the array's address up (make it once before capturing a graph).  All calls on one
+ * GPU share the array: calls that overlap in time on one GPU (two streams) race -- serialise them. */
+int fea_bce_dice_sums_static(const float* logits, const uint8_t* target, double* sums,
+                             int N, int Ccls, long long HW, void* stream);
 /* loss[0] = BCE(mean) + 1 - mean_c dice_c ; dlogits = d loss / d logits * gscale */
 int fea_bce_dice_grad(const float* logits, const uint8_t* target, const double* sums, float* loss, float* dlogits,
                       float gscale, int N, int Ccls, long long HW, void* stream);
