@@ -98,7 +98,9 @@ def roofline(prof, nrep, a):
         d[0] += ms
         d[1] += 1
         fl = 0.0
-        if name == "fea_conv3x3":
+        if name == "fea_conv3x3p":
+            fl = conv_flops(args)
+        elif name == "fea_conv3x3":
             fl = conv_flops(args)
             cout, wdt = args[11], args[9]
             # igemm_kernel<bf16, MODE 0, BN 128, EPI 0, TWS 5>: Cout % 128 == 0 and W >= 32
@@ -106,7 +108,7 @@ def roofline(prof, nrep, a):
                 dom[0] += ms; dom[1] += 1; dom[2] += fl
                 n_, h_, w_, ci_, co_ = args[7:12]
                 dom_bytes[0] += 2.0 * n_ * h_ * w_ * (ci_ + co_) + 2.0 * 9 * ci_ * co_
-        elif name == "fea_conv3x3_dgrad_bnred":
+        elif name in ("fea_conv3x3_dgrad_bnred", "fea_conv3x3p_dgrad_bnred"):
             n, h, w, cin, cout = args[12:17]
             fl = 2.0 * n * h * w * cin * cout * 9
         elif name == "fea_conv3x3_wgrad":

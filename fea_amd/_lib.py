@@ -35,6 +35,10 @@ SIGNATURES = {
     "fea_conv3x3_first_wgrad": (I, [P, I, P, P, P, Z, I, I, I, I, I, I, P]),
     "fea_conv3x3": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
     "fea_conv3x3_dgrad_bnred": (I, [P, I, P, P, I, P, I, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "fea_pack_conv3x3_frag": (I, [P, P, I, I, I, I, P]),
+    "fea_conv3x3p_rows": (I, [I, I, I, I, I, I]),
+    "fea_conv3x3p": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
+    "fea_conv3x3p_dgrad_bnred": (I, [P, I, P, P, I, P, I, P, P, P, P, P, I, I, I, I, I, I, P]),
     "fea_conv3x3_bias_relu": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "fea_conv3x3_first_bias_relu": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "fea_conv1x1": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
@@ -132,7 +136,7 @@ def call(name: str, *args):
     lib = load()
     fn = getattr(lib, name)
     conv = [ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a for a in args]
-    if PROFILE is not None and SIGNATURES[name][1] and SIGNATURES[name][1][-1] is P and not name.endswith(("_blocks", "_tiles", "_chunk", "_ksize", "_coeffs")):
+    if PROFILE is not None and SIGNATURES[name][1] and SIGNATURES[name][1][-1] is P and not name.endswith(("_blocks", "_tiles", "_chunk", "_ksize", "_coeffs", "_rows")):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*conv)
@@ -140,6 +144,6 @@ def call(name: str, *args):
         PROFILE.append((name, e0, e1, conv))
     else:
         rc = fn(*conv)
-    if SIGNATURES[name][0] is I and rc < 0 and not name.endswith(("_blocks", "_tiles", "_chunk", "_ksize", "_coeffs")):
+    if SIGNATURES[name][0] is I and rc < 0 and not name.endswith(("_blocks", "_tiles", "_chunk", "_ksize", "_coeffs", "_rows")):
         raise FeaError(f"{name} failed ({rc}): {lib.fea_last_error().decode()}")
     return rc

@@ -1,0 +1,439 @@
+// Persistent 3x3 convolution for the shallow levels (64 / 128 channels, full-resolution images), bf16, gfx950.
+//
+// The implicit-GEMM kernel of igemm.hip runs one 256-pixel tile per workgroup; at K = 9 x 64 that is ~4.6 k cycles of
+// MFMA between a prologue and an epilogue of the same length, and its 64-column variant re-streams the whole packed
+// weight (74 KB) through the vector cache for every tile.  Here ONE workgroup per CU walks a range of pixel tiles and
+// keeps the weights in REGISTERS for the kernel's life:
+//
+//   * 4 waves = 2 (pixel halves of a 8x32 tile) x 2 (32-column halves of a 64-column group); a wave owns 128 pixels x
+//     32 output channels: 8 x 2 accumulator tiles of v_mfma_f32_16x16x32_bf16, and ALL weight fragments of its 32
+//     columns (K = 576: 144 VGPRs; K = 1152: 288 VGPRs -- the kernel is built for one wave per SIMD, 512 registers);
+//   * the MFMA takes the WEIGHT fragment as its A operand and the pixel fragment as B, so an accumulator register holds
+//     4 consecutive channels of one pixel: after bf16 packing one v_permlane16_swap per dword gives every lane 8
+//     consecutive channels = one 16-byte store, with no LDS staging and no barrier in the epilogue;
+//   * pixel (halo) tiles arrive by LDS-DMA into a two-stage ring: the (8+2)x(32+2) halo of the next tile (or next
+//     64-channel chunk) is in flight while the current one is multiplied; one barrier per stage.  Tiles are walked
+//     down the image (tile row fastest), so consecutive halos share two pixel rows in L2;
+//   * BatchNorm partial sums (forward) and the fused BatchNorm-backward reduction (data gradient) are accumulated in
+//     registers over ALL tiles of the workgroup and written once per wave at the end (2 rows per workgroup instead of
+//     one row per tile): the finalize kernels read ~512 rows instead of 65,536.
+//
+// GEMM N = 128 (64 -> 128, 128 -> 128) runs as two 64-column groups on two workgroups that start on the same tiles
+// (blocks b and b + 8: the same XCD under round-robin placement, so the second reader of a halo finds it in L2).
+//
+// Reference layers: nn.Conv2d(ci, co, 3, padding=1) of enc1 / enc2 / dec2 / dec1 (models.py:10-11,19,21,28,31), forward and
+// data gradient.
+#include "common.h"
+#include <stdlib.h>
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+struct C3pArgs {
+    const __bf16* x; const __bf16* w; const float* bias; __bf16* y; float* stats;
+    long long x_img_stride, y_img_stride;     // elements per image
+    int ldx, ldy;
+    int H, W;
+    int CoutTot;                              // GEMM N of the packed weight
+    int tiles_x, tiles_y, ntiles, tiles_per_wg, npixwg, nhalf;
+    // EPI 2
+    const __bf16* ybn; int ldybn; long long ybn_img_stride;
+    const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
+    float* red_part;
+    unsigned long long* dbg;                  // C3P_STAMPS builds only: per-workgroup phase cycle sums
+};
+
+constexpr int P_TH = 8, P_TW = 32, P_HW2 = P_TW + 2;
+constexpr int P_ROWS = 352;                   // >= (8+2)*(32+2) = 340, multiple of 32
+constexpr int P_STAGE = P_ROWS * 128;         // bytes of one halo stage
+constexpr int P_NDMA = 11;                    // 1 KB LDS-DMA pieces per wave per stage (44 pieces)
+
+__device__ __forceinline__ int p_swz(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// EPI 0: y = conv + bias (bias nullable); STATS 2: BatchNorm partial sums (sum y, sum y^2), STATS 1: sum y only (slot 1
+//        is written as 0: the ConvTranspose2d bias gradient taken from a data-gradient launch), STATS 0: none
+// EPI 2: da = conv (no bias) + fused first pass of the next BatchNorm backward (sum g, sum g*xhat)
+template <int NCH, int EPI, int STATS>
+__global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
+    constexpr int YB = EPI == 2 ? 4 * 8192 : 0;        // per-wave private y tiles (128 px x 64 B)
+    __shared__ __attribute__((aligned(128))) char smem[2 * P_STAGE + YB + 256];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform: LDS-DMA bases stay scalar
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, q16 = lane >> 4;
+    int pw, half;
+    if (g.nhalf == 2 && (g.npixwg & 7) == 0) { half = (blockIdx.x >> 3) & 1; pw = (blockIdx.x & 7) + 8 * (blockIdx.x >> 4); }
+    else { half = blockIdx.x / g.npixwg; pw = blockIdx.x - half * g.npixwg; }
+    const int W = g.W;
+    const int cbase = half * 64 + wn * 32;              // first GEMM column of this wave
+
+    // ---- weights: all fragments of this wave's 32 columns, for the kernel's life ------------------
+    // packed [kc = chunk*9 + tap][col/16][ks][lane][8]
+    u32x4 Wf[NCH][9][2][2];
+    {
+        const __bf16* wb = g.w + (long long)lane * 8;
+        const int nt16 = g.CoutTot >> 4;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        Wf[c][tap][ks][n] = *reinterpret_cast<const u32x4*>(
+                            wb + ((long long)((c * 9 + tap) * nt16 + (cbase >> 4) + n) * 2 + ks) * 512);
+    }
+
+    // ---- A (pixel) fragment addresses: halo rows wm*4 .. wm*4+5, dx 0..2, x = r16 (odd m: +2048 bytes) ----
+    uint32_t abase[6][3];
+#pragma unroll
+    for (int hr = 0; hr < 6; ++hr)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int row = (wm * 4 + hr) * P_HW2 + r16 + dx;
+            abase[hr][dx] = row * 128 + ((q16 ^ p_swz(row)) << 4);
+        }
+
+    // ---- LDS-DMA descriptors: piece j = 4 i + wave fills LDS rows 8 j .. 8 j + 7 (lane -> row 8j + lane/8, slot lane%8)
+    int rel[P_NDMA];
+    unsigned fl0 = 0, fl1 = 0;       // 5 flag bits per piece: top, bottom, left, right halo line, padding row
+#pragma unroll
+    for (int i = 0; i < P_NDMA; ++i) {
+        const int row = (4 * i + wave) * 8 + (lane >> 3);
+        const int hy = row / P_HW2, hx = row - hy * P_HW2;
+        const int chunk = (lane & 7) ^ p_swz(row);
+        rel[i] = ((hy - 1) * W + (hx - 1)) * g.ldx * 2 + chunk * 16;
+        const unsigned f = (hy == 0 ? 1u : 0u) | (hy == P_TH + 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == P_TW + 1 ? 8u : 0u) |
+                           (row >= (P_TH + 2) * P_HW2 ? 16u : 0u);
+        if (i < 6) fl0 |= f << (5 * i); else fl1 |= f << (5 * (i - 6));
+    }
+    // Pieces are buffer loads (LDS-DMA form): the descriptor covers ONE image, a lane's offset is tile origin + rel, and
+    // lanes that must read zero padding get an out-of-range offset (the hardware returns 0 for them) -- no select
+    // between two 64-bit addresses, 4 VALU per piece.
+    const unsigned img_bytes = (unsigned)(g.x_img_stride * 2);
+    auto tile_rsrc = [&](int n_img) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(g.x + (long long)n_img * g.x_img_stride), 0, (int)img_bytes, 0x00020000);
+    };
+    auto tile_off = [&](int tx, int ty, int c) -> int { return ((ty * P_TH) * W + tx * P_TW) * g.ldx * 2 + c * 128; };
+    auto tile_edge = [&](int tx, int ty) -> unsigned {
+        return (ty == 0 ? 1u : 0u) | (ty == g.tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == g.tiles_x - 1 ? 8u : 0u) | 16u;
+    };
+    auto issue_piece = [&](__amdgpu_buffer_rsrc_t rs, int toff, unsigned edge, int stage, auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const unsigned f = ((i < 6 ? fl0 >> (5 * i) : fl1 >> (5 * (i - 6))) & edge) & 31u;
+        const int voff = f ? (int)0xfffffff0u : toff + rel[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + stage * P_STAGE + (4 * i + wave) * 1024), 16, voff, 0, 0, 0);
+    };
+    auto issue = [&](int n_img, int tx, int ty, int c, int stage) {
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(n_img);
+        const int toff = tile_off(tx, ty, c);
+        const unsigned edge = tile_edge(tx, ty);
+        sfor<0, P_NDMA>([&](auto ic) { issue_piece(rs, toff, edge, stage, ic); });
+    };
+
+    // ---- output addressing: lane's pixel (tile row wm*4 + (m>>1), x = (m&1)*16 + r16), 8 channels from chl -------
+    const int chl = (q16 & 1) * 16 + (q16 >> 1) * 8;     // q: 0 -> 0, 1 -> 16, 2 -> 8, 3 -> 24 (after the lane exchange)
+    const long long y_lane = ((long long)(wm * 4) * W + r16) * g.ldy + cbase + chl;
+
+    // ---- per-channel state -------------------------------------------------------------------------------
+    // bias of the 64-column group in LDS (after the stages): read back as the C operand of a tile's first MFMAs, so
+    // it occupies registers only for the first k-step of each tile
+    float* const blds = reinterpret_cast<float*>(smem + 2 * P_STAGE + YB);
+    if (tid < 64) blds[tid] = (EPI == 0 && g.bias) ? g.bias[half * 64 + tid] : 0.f;
+    __syncthreads();
+    f32x4 S[2], Q[2];                 // EPI 0: sum y, sum y^2 of channels cbase + 16 n + 4 q + e
+    float a0[8], a1[8], csc[8], csh[8];   // EPI 2: channels cbase + chl + j
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        S[n] = f32x4{0.f, 0.f, 0.f, 0.f}; Q[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a0[j] = 0.f; a1[j] = 0.f;
+        csc[j] = EPI == 2 ? g.bn_scale[cbase + chl + j] : 0.f;
+        csh[j] = EPI == 2 ? g.bn_shift[cbase + chl + j] : 0.f;
+    }
+    long long ybn_lane = 0;
+    char* const ylds = smem + 2 * P_STAGE + wave * 8192;
+    if constexpr (EPI == 2) ybn_lane = ((long long)(wm * 4) * W) * g.ldybn + cbase;
+
+    f32x4 acc[8][2];
+    // the first k-step of a tile takes the bias as its C operand: the accumulators are never re-initialised
+    const uint32_t bias_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + 2 * P_STAGE + YB + (wn * 32 + 4 * q16) * 4;
+
+    // one stage: 9 taps x 2 k-steps of 32.  The A (pixel) fragment of tile m is re-read for the NEXT k-step right after
+    // its two MFMAs of this k-step, so 7 reads are always in flight behind the one an MFMA needs: the LDS reads are
+    // inline asm in a fixed order (the LDS returns them in order) retired by a constant counted wait, lgkmcnt(7).
+    // `between(step)` is called once per k-step behind its MFMAs (the LDS-DMA pieces of the next stage go there).
+    auto lds_rd = [&](u32x4& dst, uint32_t addr, auto offc) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(offc)::value) : "memory");
+    };
+    auto mma_stage = [&](auto cc, auto sc_, auto&& hook) {
+        constexpr int C = decltype(cc)::value, STG = decltype(sc_)::value;
+        const uint32_t st = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        u32x4 A[8], bq[2];
+        if constexpr (C == 0) {      // two more reads in front of the ring: retired by the first counted wait
+            lds_rd(bq[0], bias_addr, std::integral_constant<int, 0>{});
+            lds_rd(bq[1], bias_addr, std::integral_constant<int, 64>{});
+        }
+        sfor<0, 8>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            lds_rd(A[m], st + abase[m >> 1][0], std::integral_constant<int, STG * P_STAGE + (m & 1) * 2048>{});
+        });
+        f32x4 biasv[2];
+        if constexpr (C == 0) {
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bq[0]), "+v"(bq[1]));
+            biasv[0] = __builtin_bit_cast(f32x4, bq[0]); biasv[1] = __builtin_bit_cast(f32x4, bq[1]);
+        }
+        sfor<0, 18>([&](auto stc) {
+            constexpr int step = decltype(stc)::value, tap = step >> 1, ks = step & 1;
+            constexpr int nstep = step + 1, ntap = nstep >> 1, nks = nstep & 1, ndy = ntap / 3, ndx = ntap % 3;
+            sfor<0, 8>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                if constexpr (nstep < 18) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(A[m]));
+                else                      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(A[m]) : "n"(7 - m));
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[C][tap][ks][n]),
+                                                                        __builtin_bit_cast(bf16x8, A[m]),
+                                                                        (C == 0 && step == 0) ? biasv[n] : acc[m][n], 0, 0, 0);
+                if constexpr (nstep < 18)
+                    lds_rd(A[m], st + (abase[(m >> 1) + ndy][ndx] ^ (uint32_t)(nks << 6)),
+                           std::integral_constant<int, STG * P_STAGE + (m & 1) * 2048>{});
+                hook(stc, mc);
+            });
+        });
+    };
+
+    // ---- tile walk ----------------------------------------------------------------------------------------
+    const int t0 = pw * g.tiles_per_wg;
+    const int t1 = min(t0 + g.tiles_per_wg, g.ntiles);
+    int ty = t0 % g.tiles_y, tx = (t0 / g.tiles_y) % g.tiles_x, ni = t0 / (g.tiles_y * g.tiles_x);
+    auto advance = [&](int& n_, int& x_, int& y_) {
+        if (++y_ == g.tiles_y) { y_ = 0; if (++x_ == g.tiles_x) { x_ = 0; ++n_; } }
+    };
+    if (t0 < t1) issue(ni, tx, ty, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#ifdef C3P_STAMPS
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define STAMP(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[k] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+    // work item = (tile, chunk); stage = item & 1
+    auto item = [&](int t, auto cc, auto sc_) {
+        constexpr int C = decltype(cc)::value, STG = decltype(sc_)::value;
+        STAMP(4);
+        // this wave's DMA pieces of this stage have landed (the vmcnt(0) behind the previous stage's MFMAs / the
+        // prologue); after the barrier every wave's have, and every wave is done reading the other stage
+        __builtin_amdgcn_s_barrier();
+        STAMP(0);
+        // next item into the other stage: its 11 pieces are issued behind every second MFMA pair of the first three
+        // k-steps (mma_stage), early enough to land during this stage and spread so that their address arithmetic
+        // issues in the shadow of the MFMAs
+        int n2 = ni, x2 = tx, y2 = ty;
+        if constexpr (C + 1 == NCH) advance(n2, x2, y2);
+        const bool more = (C + 1 < NCH) || (t + 1 < t1);
+        const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(more ? n2 : ni);
+        const int ntoff = tile_off(x2, y2, (C + 1) % NCH);
+        const unsigned nedge = more ? tile_edge(x2, y2) : 31u;          // nothing follows: every lane reads "padding" (zeros)
+        if constexpr (EPI == 2 && C == NCH - 1) {
+            // this tile's pre-BN activations, the 64-byte rows this wave will read itself: 16 pixels x 64 B per piece
+            const __bf16* yb = g.ybn + (long long)ni * g.ybn_img_stride + ((long long)(ty * P_TH) * W + tx * P_TW) * g.ldybn + ybn_lane;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const __bf16* src = yb + ((long long)(m >> 1) * W + (m & 1) * 16 + (lane >> 2)) * g.ldybn + (lane & 3) * 8;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ylds + m * 1024), 16, 0, 0);
+            }
+        }
+        mma_stage(cc, sc_, [&](auto stc, auto mc) {
+            constexpr int step = decltype(stc)::value, m = decltype(mc)::value, piece = step * 4 + (m >> 1);
+            if constexpr ((m & 1) == 1 && piece < P_NDMA) issue_piece(nrs, ntoff, nedge, STG ^ 1, std::integral_constant<int, piece>{});
+        });
+        // the next stage's pieces (and this tile's y pieces) were issued a whole MFMA phase ago, the previous tile's
+        // stores before that: this wait is (nearly) free and the epilogue's stores below are never waited for
+        STAMP(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(2);
+        if constexpr (C == NCH - 1) {
+            __bf16* yt = g.y + (long long)ni * g.y_img_stride + ((long long)(ty * P_TH) * W + tx * P_TW) * g.ldy + y_lane;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if constexpr (EPI == 0 && STATS >= 1) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        S[n] += acc[m][n];
+                        if constexpr (STATS == 2) Q[n] = __builtin_elementwise_fma(acc[m][n], acc[m][n], Q[n]);
+                    }
+                }
+                uint32_t lo0 = pack_bf16x2(acc[m][0][0], acc[m][0][1]), hi0 = pack_bf16x2(acc[m][0][2], acc[m][0][3]);
+                uint32_t lo1 = pack_bf16x2(acc[m][1][0], acc[m][1][1]), hi1 = pack_bf16x2(acc[m][1][2], acc[m][1][3]);
+                // odd 16-lane rows of the first operand <-> even rows of the second: every lane ends up with 8 consecutive channels
+                const auto r0 = __builtin_amdgcn_permlane16_swap(lo0, lo1, false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(hi0, hi1, false, false);
+                const u32x4 out = {r0[0], r1[0], r0[1], r1[1]};
+                *reinterpret_cast<u32x4*>(yt + ((long long)(m >> 1) * W + (m & 1) * 16) * g.ldy) = out;
+                if constexpr (EPI == 2) {
+                    // lane (pixel r16 of tile m, channels chl..chl+7): y row at ylds + m*1024 + r16*64 + piece*16
+                    const u32x4 yv = *reinterpret_cast<const u32x4*>(ylds + m * 1024 + r16 * 64 + (chl >> 3) * 16);
+                    const bf16x8 yy = __builtin_bit_cast(bf16x8, yv), dd = __builtin_bit_cast(bf16x8, out);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float yf = (float)yy[j];
+                        const float gg = __builtin_fmaf(yf, csc[j], csh[j]) > 0.f ? (float)dd[j] : 0.f;
+                        a0[j] += gg; a1[j] = __builtin_fmaf(gg, yf, a1[j]);
+                    }
+                }
+            }
+            advance(ni, tx, ty);
+            STAMP(3);
+        }
+    };
+
+    if constexpr (NCH == 1) {
+        for (int t = t0; t < t1; t += 2) {
+            item(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            if (t + 1 < t1) item(t + 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            else break;
+        }
+    } else {
+        for (int t = t0; t < t1; ++t) {
+            item(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            item(t, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        }
+    }
+
+#ifdef C3P_STAMPS
+    if (lane == 0 && g.dbg) for (int k = 0; k < 5; ++k) g.dbg[(blockIdx.x * 4 + wave) * 5 + k] = ph[k];
+#endif
+    // ---- per-wave partial sums: row 2 pw + wm, this wave's 32 columns ----------------------------------------
+    const int row = pw * 2 + wm;
+    if constexpr (EPI == 0) {
+        if constexpr (STATS >= 1) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float s = S[n][e], q = Q[n][e];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+                    if (r16 == 0) {
+                        float* dst = g.stats + ((long long)row * g.CoutTot + cbase + 16 * n + 4 * q16 + e) * 2;
+                        dst[0] = s; dst[1] = q;
+                    }
+                }
+        }
+    } else if constexpr (EPI == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float s0 = a0[j], s1 = a1[j];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+            if (r16 == 0) {
+                const int ch = cbase + chl + j;
+                // sum g*xhat = invstd * (sum g*y - mean * sum g)
+                float* dst = g.red_part + ((long long)row * g.CoutTot + ch) * 2;
+                dst[0] = s0; dst[1] = g.bn_invstd[ch] * (s1 - g.bn_mean[ch] * s0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+struct C3pPlan { int tiles_x, tiles_y, ntiles, nhalf, npixwg, tiles_per_wg; };
+
+static bool c3p_plan(int N, int H, int W, int Cin, int Cout, int dtype, C3pPlan& p) {
+    if (dtype != FEA_BF16 || (Cin != 64 && Cin != 128) || (Cout != 64 && Cout != 128)) return false;
+    if (H % P_TH || W % P_TW || N <= 0) return false;
+    p.tiles_x = W / P_TW; p.tiles_y = H / P_TH;
+    const long long nt = (long long)N * p.tiles_x * p.tiles_y;
+    if (nt >= (1ll << 30)) return false;
+    p.ntiles = (int)nt;
+    p.nhalf = Cout / 64;
+    int want = 256 / p.nhalf;                 // one workgroup per CU
+    if (want > p.ntiles) want = p.ntiles;
+    p.tiles_per_wg = (p.ntiles + want - 1) / want;
+    p.npixwg = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+    return true;
+}
+
+// rows of the partial-sum tables (stats / part) the persistent kernels write; 0 = shape not served by them
+extern "C" int fea_conv3x3p_rows(int N, int H, int W, int Cin, int Cout, int dtype) {
+    C3pPlan p;
+    if (!c3p_plan(N, H, W, Cin, Cout, dtype, p)) return 0;
+    return p.npixwg * 2;
+}
+
+static int c3p_check(const char* who, const void* x, int ldx, const void* w, const void* y, int ldy, int N, int H, int W,
+                     int Cin, int Cout, int dtype, C3pPlan& p) {
+    FEA_CHECK(x && w && y, FEA_E_BADARG, "%s: null pointer", who);
+    FEA_CHECK(c3p_plan(N, H, W, Cin, Cout, dtype, p), FEA_E_UNSUPPORTED_SHAPE,
+              "%s: serves bf16, Cin and Cout in {64,128}, H %% 8 == 0, W %% 32 == 0 (got N=%d H=%d W=%d Cin=%d Cout=%d): use fea_conv3x3",
+              who, N, H, W, Cin, Cout);
+    FEA_CHECK(ldx >= Cin && ldy >= Cout && ldx % 8 == 0 && ldy % 8 == 0, FEA_E_BADARG, "%s: ldx=%d ldy=%d", who, ldx, ldy);
+    FEA_CHECK(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)w % 16 == 0), FEA_E_BADARG, "%s: pointers must be 16-byte aligned", who);
+    FEA_CHECK((long long)(H + 2) * W * ldx * 2 < (1ll << 31) && (long long)H * W * ldy * 2 < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE,
+              "%s: image too large for 32-bit in-image offsets", who);
+    return FEA_OK;
+}
+
+static void c3p_fill(C3pArgs& a, const C3pPlan& p, const void* x, int ldx, const void* w, void* y, int ldy, int H, int W, int Cout) {
+    a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.y = (__bf16*)y;
+    a.ldx = ldx; a.ldy = ldy; a.H = H; a.W = W; a.CoutTot = Cout;
+    a.x_img_stride = (long long)H * W * ldx; a.y_img_stride = (long long)H * W * ldy;
+    a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_wg = p.tiles_per_wg;
+    a.npixwg = p.npixwg; a.nhalf = p.nhalf;
+}
+
+extern "C" int fea_conv3x3p(const void* x, int ldx, const void* w_frag, const float* bias, void* y, int ldy, float* stats,
+                            int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    C3pPlan p;
+    int rc = c3p_check("fea_conv3x3p", x, ldx, w_frag, y, ldy, N, H, W, Cin, Cout, dtype, p);
+    if (rc) return rc;
+    C3pArgs a{};
+    c3p_fill(a, p, x, ldx, w_frag, y, ldy, H, W, Cout);
+    a.bias = bias; a.stats = stats;
+#ifdef C3P_STAMPS
+    a.dbg = (unsigned long long*)getenv("C3P_DBG_PTR") ? (unsigned long long*)strtoull(getenv("C3P_DBG_PTR"), nullptr, 0) : nullptr;
+#endif
+    dim3 grid((unsigned)(p.npixwg * p.nhalf)), block(256);
+    // forward (bias given): sum y and sum y^2; data gradient (no bias): sum only (the ConvTranspose2d bias gradient)
+    const int st = !stats ? 0 : (bias ? 2 : 1);
+#define C3P_LAUNCH(NCHV, STV) hipLaunchKernelGGL((c3p_kernel<NCHV, 0, STV>), grid, block, 0, (hipStream_t)stream, a)
+    if (Cin == 64) { if (st == 2) C3P_LAUNCH(1, 2); else if (st == 1) C3P_LAUNCH(1, 1); else C3P_LAUNCH(1, 0); }
+    else           { if (st == 2) C3P_LAUNCH(2, 2); else if (st == 1) C3P_LAUNCH(2, 1); else C3P_LAUNCH(2, 0); }
+#undef C3P_LAUNCH
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_conv3x3p_dgrad_bnred(const void* dy, int lddy, const void* w_frag, void* da, int ldda,
+                                        const void* y, int ldy_bn, const float* scale, const float* shift,
+                                        const float* save_mean, const float* save_invstd, float* part,
+                                        int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    C3pPlan p;
+    const char* who = "fea_conv3x3p_dgrad_bnred";
+    int rc = c3p_check(who, dy, lddy, w_frag, da, ldda, N, H, W, Cin, Cout, dtype, p);
+    if (rc) return rc;
+    FEA_CHECK(y && scale && shift && save_mean && save_invstd && part, FEA_E_BADARG, "%s: null pointer", who);
+    FEA_CHECK(ldy_bn >= Cout && ldy_bn % 8 == 0 && ((uintptr_t)y % 16 == 0) && (long long)H * W * ldy_bn * 2 < (1ll << 31), FEA_E_BADARG, "%s: y layout", who);
+    C3pArgs a{};
+    c3p_fill(a, p, dy, lddy, w_frag, da, ldda, H, W, Cout);
+    a.ybn = (const __bf16*)y; a.ldybn = ldy_bn; a.ybn_img_stride = (long long)H * W * ldy_bn;
+    a.bn_scale = scale; a.bn_shift = shift; a.bn_mean = save_mean; a.bn_invstd = save_invstd; a.red_part = part;
+    dim3 grid((unsigned)(p.npixwg * p.nhalf)), block(256);
+    if (Cin == 64) hipLaunchKernelGGL((c3p_kernel<1, 2, 0>), grid, block, 0, (hipStream_t)stream, a);
+    else           hipLaunchKernelGGL((c3p_kernel<2, 2, 0>), grid, block, 0, (hipStream_t)stream, a);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}

@@ -95,7 +95,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
 //         = the 16x16x32 MFMA B fragments in the order the conv kernel's waves load them
 //         (one contiguous KB per wave-instruction, global -> VGPR)
 template <typename T>
-__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int dgrad) {
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int dgrad, int force_frag) {
     constexpr int CK = Elem<T>::CK;
     const int rows = dgrad ? Ci : Co;          // GEMM N
     const int kch = dgrad ? Co : Ci;           // GEMM K channels
@@ -103,7 +103,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int row, kk, kc;
-    if (fea_conv3x3_frag_pack(rows, sizeof(T))) {
+    if (force_frag || fea_conv3x3_frag_pack(rows, sizeof(T))) {
         const int j = (int)(i & 7), ln = (int)((i >> 3) & 63), ks = (int)((i >> 9) & 1);
         const long long blk = i >> 10;
         const int nt16 = rows >> 4;
@@ -544,7 +544,17 @@ extern "C" int fea_pack_conv3x3(const float* w, void* out, int Co, int Ci, int d
     FEA_CHECK((dgrad ? Co : Ci) % CK == 0, FEA_E_UNSUPPORTED_SHAPE, "fea_pack_conv3x3: K channels not a multiple of %d", CK);
     const long long total = (long long)9 * Co * Ci;
     DT_SWITCH(dtype, "fea_pack_conv3x3",
-              hipLaunchKernelGGL((pack_conv3x3_kernel<T>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, w, (T*)out, Co, Ci, dgrad));
+              hipLaunchKernelGGL((pack_conv3x3_kernel<T>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, w, (T*)out, Co, Ci, dgrad, 0));
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+// always MFMA fragment order (the persistent kernels of conv_p.hip keep the fragments in registers), bf16
+extern "C" int fea_pack_conv3x3_frag(const float* w, void* out, int Co, int Ci, int dgrad, int dtype, void* stream) {
+    FEA_CHECK(w && out && Co > 0 && Ci > 0 && dtype == FEA_BF16, FEA_E_BADARG, "fea_pack_conv3x3_frag: bad args (bf16 only)");
+    FEA_CHECK(Co % 64 == 0 && Ci % 64 == 0, FEA_E_UNSUPPORTED_SHAPE, "fea_pack_conv3x3_frag: channels must be multiples of 64");
+    const long long total = (long long)9 * Co * Ci;
+    hipLaunchKernelGGL((pack_conv3x3_kernel<__bf16>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)out, Co, Ci, dgrad, 1);
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }

@@ -73,6 +73,13 @@ def param_order(module) -> List[str]:
     return names
 
 
+def _table_rows(N, h, w) -> int:
+    """Upper bound of the rows of a conv kernel's partial-sum table (`stats` / `part`): one per pixel tile for the
+    one-tile-per-workgroup kernels, two per workgroup (at most 2 x 256, at most 2 per tile) for the persistent ones."""
+    nt = L.call("fea_conv_num_tiles", N, h, w)
+    return max(nt, min(512, 2 * N * ((h + 7) // 8) * ((w + 31) // 32)))
+
+
 class _Plan:
     """All device buffers for one (N, H, W) problem."""
 
@@ -100,7 +107,7 @@ class _Plan:
             if blk not in ENC:
                 self.a3[blk] = es((N, h, w, c), dtype=dt, device=dev)
             # forward: Cout columns; decoder dgrad of X.0 also takes sums of its 2*Cout-wide output
-            max_stats = max(max_stats, L.call("fea_conv_num_tiles", N, h, w) * (c if blk in ENC or blk == "bottleneck" else 2 * c) * 2)
+            max_stats = max(max_stats, _table_rows(N, h, w) * (c if blk in ENC or blk == "bottleneck" else 2 * c) * 2)
         for k, blk in enumerate(ENC, start=1):
             h, w = self.dims[k - 1]
             c = CH[blk]
@@ -174,7 +181,7 @@ class _Plan:
         # rows of `part`: the BN-backward kernels use fea_bn_bwd_blocks() rows, the fused
         # dgrad epilogue (fea_conv3x3_dgrad_bnred) one row per conv pixel tile
         nb = max(max(L.call("fea_bn_bwd_blocks", N, *self.dims[LEVEL[b]], CH[b]),
-                     L.call("fea_conv_num_tiles", N, *self.dims[LEVEL[b]])) * CH[b] * 2 for b in BLOCKS)
+                     _table_rows(N, *self.dims[LEVEL[b]])) * CH[b] * 2 for b in BLOCKS)
         nb = max(nb, 2048 * 1024 * 2)
         self.part = es(nb, dtype=torch.float32, device=dev)
         self.bncoef = es(1024 * 2, dtype=torch.float32, device=dev)
@@ -221,6 +228,9 @@ class UNetEngine:
         self._wstream = None
         self._P: Dict[str, torch.Tensor] = {}
         self._B: Dict[str, torch.Tensor] = {}
+        # persistent conv kernels for the shallow levels (bf16); FEA_AMD_PERSISTENT=0 selects the plain kernels (A/B runs)
+        self.use_persistent = compute_dtype == torch.bfloat16 and os.environ.get("FEA_AMD_PERSISTENT", "1") != "0"
+        self._p_rows_cache: Dict[tuple, int] = {}
         self.backward_count = 0        # backward passes run so far (ClipAdamW checks that it steps on one backward's gradients)
         L.load()
 
@@ -307,8 +317,21 @@ class UNetEngine:
         """Forget packed weights (call after parameters were changed in place)."""
         self._gen += 1
 
-    def _w_fwd(self, name: str):
+    def _p_rows(self, N, h, w, cin, cout) -> int:
+        """Rows of the partial-sum tables of the persistent conv kernels (csrc/conv_p.hip) for this
+        GEMM shape, 0 when they do not serve it (then the one-tile-per-workgroup kernels run)."""
+        if not self.use_persistent:
+            return 0
+        key = (N, h, w, cin, cout)
+        r = self._p_rows_cache.get(key)
+        if r is None:
+            r = self._p_rows_cache[key] = L.call("fea_conv3x3p_rows", N, h, w, cin, cout, self.code)
+        return r
+
+    def _w_fwd(self, name: str, frag: bool = False):
         p = self._P[name + ".weight"]
+        if frag:
+            return self._pack(name + "/fp", p, p.numel(), "fea_pack_conv3x3_frag", p.shape[0], p.shape[1], 0)
         if name == "enc1.0" and self.first_direct:
             ks = (9 * self.in_channels + 31) // 32
             return self._pack(name + "/f", p, ks * 64 * 32, "fea_pack_conv3x3_first", 64, self.in_channels)
@@ -345,10 +368,29 @@ class UNetEngine:
             self.folded[name] = ent
         return ent[1], ent[2]
 
-    def _w_dgrad(self, name: str):
+    def _w_dgrad(self, name: str, frag: bool = False):
         p = self._P[name + ".weight"]
         co, ci = p.shape[0], p.shape[1]
+        if frag:
+            return self._pack(name + "/dp", p, p.numel(), "fea_pack_conv3x3_frag", co, ci, 1)
         return self._pack(name + "/d", p, p.numel(), "fea_pack_conv3x3", co, ci, 1)
+
+    def _p_modes(self, pl: "_Plan"):
+        """Per conv layer: (rows of the persistent forward kernel, rows of the persistent data-gradient kernel), 0 = not
+        served.  X.3 layers' data gradient is the fused-BatchNorm-reduction kernel, served for 64 channels only."""
+        modes = getattr(pl, "p_modes", None)
+        if modes is None:
+            modes = {}
+            for blk in BLOCKS:
+                h, w = pl.dims[LEVEL[blk]]
+                c, cin = CH[blk], self.block_cin(blk)
+                f0 = self._p_rows(pl.N, h, w, cin, c) if blk != "enc1" else 0
+                d0 = self._p_rows(pl.N, h, w, c, cin) if blk != "enc1" else 0
+                f3 = self._p_rows(pl.N, h, w, c, c)
+                d3 = f3 if c == 64 else 0
+                modes[f"{blk}.0"], modes[f"{blk}.3"] = (f0, d0), (f3, d3)
+            pl.p_modes = modes
+        return modes
 
     def _w_up(self, name: str, bwd: int):
         p = self._P[name + ".weight"]
@@ -389,12 +431,13 @@ class UNetEngine:
                 self._wstream = torch.cuda.Stream(device=self.device)
             ev0 = torch.cuda.Event()
             ev0.record(main)
+            pm = self._p_modes(pl)
             with torch.cuda.stream(self._wstream):
                 self._wstream.wait_event(ev0)
                 for blk in BLOCKS:
                     for idx in (0, 3):
                         if not (blk == "enc1" and idx == 0):
-                            self._w_fwd(f"{blk}.{idx}")
+                            self._w_fwd(f"{blk}.{idx}", frag=pm[f"{blk}.{idx}"][0] > 0)
                 for k in (1, 2, 3, 4):
                     self._w_up(f"upconv{k}", 0)
                 packs_done = torch.cuda.Event()
@@ -402,7 +445,7 @@ class UNetEngine:
                 for blk in BLOCKS:
                     for idx in (0, 3):
                         if not (blk == "enc1" and idx == 0):
-                            self._w_dgrad(f"{blk}.{idx}")
+                            self._w_dgrad(f"{blk}.{idx}", frag=pm[f"{blk}.{idx}"][1] > 0)
                 for k in (1, 2, 3, 4):
                     self._w_up(f"upconv{k}", 1)
                 pl.bwd_packs_done = torch.cuda.Event()
@@ -430,9 +473,12 @@ class UNetEngine:
             if packs_done is not None and name != "enc1.0" and not waited[0]:
                 torch.cuda.current_stream().wait_event(packs_done)
                 waited[0] = True
-            wp = self._w_fwd(name)
+            rows_p = self._p_modes(pl)[name][0] if training else 0
+            wp = self._w_fwd(name, frag=rows_p > 0)
             bias = P[name + ".bias"]
-            if name == "enc1.0" and self.first_direct:
+            if rows_p:
+                L.call("fea_conv3x3p", inp, ld_in, wp, bias, y, cout, stats, N, h, w, cin, cout, code, S)
+            elif name == "enc1.0" and self.first_direct:
                 L.call("fea_conv3x3_first", pl.x_in, wp, bias, y, cout, stats, N, self.in_channels, h, w, cout, code, S)
             elif name == "enc1.0":
                 L.call("fea_conv1x1", inp, ld_in, wp, bias, y, cout, stats, N, h, w, self.kpad, cout, code, S)
@@ -442,7 +488,7 @@ class UNetEngine:
             bn = f"{blk}.{int(idx) + 1}"
             cf = pl.coef[name]
             if training:
-                ntiles = L.call("fea_conv_num_tiles", N, h, w)
+                ntiles = rows_p or L.call("fea_conv_num_tiles", N, h, w)
                 L.call("fea_bn_finalize", stats, ntiles, N * h * w, P[bn + ".weight"], P[bn + ".bias"],
                        B[bn + ".running_mean"], B[bn + ".running_var"], BN_MOMENTUM, BN_EPS,
                        cf["scale"], cf["shift"], cf["mean"], cf["invstd"], cout, S)
@@ -570,6 +616,7 @@ class UNetEngine:
                 done(*names)
 
         fuse = self.dtype == torch.bfloat16     # dgrad kernels also produce the next BN-backward's partial sums
+        pm = self._p_modes(pl)
 
         def bn_bwd(name, da_full, ld_da, dpool, h, w, c, reduced_tiles=0):
             """reduced_tiles > 0: pl.part already holds that many per-tile partial sums
@@ -607,17 +654,21 @@ class UNetEngine:
 
             if fuse:
                 cf0 = pl.coef[n0]
-                L.call("fea_conv3x3_dgrad_bnred", ring["dY"], c, self._w_dgrad(n3), pl.gmid, c, pl.y[n0], c,
+                rows_p = pm[n3][1]
+                L.call("fea_conv3x3p_dgrad_bnred" if rows_p else "fea_conv3x3_dgrad_bnred", ring["dY"], c,
+                       self._w_dgrad(n3, frag=rows_p > 0), pl.gmid, c, pl.y[n0], c,
                        cf0["scale"], cf0["shift"], cf0["mean"], cf0["invstd"], pl.part, N, h, w, c, c, code, S)
                 wg3()
-                bn_bwd(n0, pl.gmid, c, None, h, w, c, reduced_tiles=L.call("fea_conv_num_tiles", N, h, w))
+                bn_bwd(n0, pl.gmid, c, None, h, w, c, reduced_tiles=rows_p or L.call("fea_conv_num_tiles", N, h, w))
             else:
                 L.call("fea_conv3x3", ring["dY"], c, self._w_dgrad(n3), None, pl.gmid, c, None, N, h, w, c, c, code, S)
                 wg3()
                 bn_bwd(n0, pl.gmid, c, None, h, w, c)
             names0 = (n0 + ".weight", n0 + ".bias", f"{blk}.1.weight", f"{blk}.1.bias")
             if d_in is not None:             # dgrad first, see wg3()
-                L.call("fea_conv3x3", ring["dY"], c, self._w_dgrad(n0), None, d_in, ld_din, din_stats, N, h, w, c, cin, code, S)
+                rows_p = pm[n0][1]
+                L.call("fea_conv3x3p" if rows_p else "fea_conv3x3", ring["dY"], c, self._w_dgrad(n0, frag=rows_p > 0), None,
+                       d_in, ld_din, din_stats, N, h, w, c, cin, code, S)
             if blk == "enc1" and self.first_direct:
                 wgrad("fea_conv3x3_first_wgrad", (ring["dY"], c, pl.x_in, g[n0 + ".weight"], pl.ws, pl.ws_bytes,
                                                   N, self.in_channels, h, w, c, code), names0)
@@ -642,7 +693,7 @@ class UNetEngine:
             block_bwd(blk, pl.G[0], c, None, pl.cat[k], 2 * c, 2 * c, pl.dcat[k], 2 * c, din_stats=pl.stats, reduced_tiles=pre)
             hl, wl = pl.dims[k]
             src = pl.a3[f"dec{k + 1}"] if k < 4 else pl.a3["bottleneck"]
-            L.call("fea_reduce_partials_n", pl.stats, L.call("fea_conv_num_tiles", N, 2 * hl, 2 * wl), 2 * c, c, 0,
+            L.call("fea_reduce_partials_n", pl.stats, pm[f"{blk}.0"][1] or L.call("fea_conv_num_tiles", N, 2 * hl, 2 * wl), 2 * c, c, 0,
                    g[f"upconv{k}.bias"], S)
             wgrad("fea_upconv2x2_wgrad", (src, 2 * c, pl.dcat[k], 2 * c, g[f"upconv{k}.weight"], pl.ws, pl.ws_bytes,
                                           N, hl, wl, 2 * c, c, code), (f"upconv{k}.weight", f"upconv{k}.bias"), reads_dY=False)

@@ -53,12 +53,22 @@ def main():
         if a.op == "conv":
             entry = a.entry or "fea_conv3x3"
             wp = torch.empty(9 * co * ci, dtype=dt, device="cuda")
-            L.call("fea_pack_conv3x3", wt, wp, co, ci, 0, code, S)
+            L.call("fea_pack_conv3x3_frag" if entry == "fea_conv3x3p" else "fea_pack_conv3x3", wt, wp, co, ci, 0, code, S)
             y = torch.empty(n, h, w, co, dtype=dt, device="cuda")
             bias = torch.zeros(co, device="cuda")
             nt = L.call("fea_conv_num_tiles", n, h, w)
             stats = torch.empty(nt * co * 2, device="cuda") if a.stats else None
             fn = lambda: L.call(entry, x, ci, wp, bias, y, co, stats, n, h, w, ci, co, code, S)  # noqa: E731
+        elif a.op == "bnred":
+            entry = a.entry or "fea_conv3x3_dgrad_bnred"
+            wp = torch.empty(9 * co * ci, dtype=dt, device="cuda")
+            L.call("fea_pack_conv3x3_frag" if entry.startswith("fea_conv3x3p") else "fea_pack_conv3x3", wt, wp, co, ci, 0, code, S)
+            y = torch.empty(n, h, w, co, dtype=dt, device="cuda")
+            yb = torch.randn(n, h, w, co, device="cuda", generator=g).to(dt)
+            cf = [torch.randn(co, device="cuda") for _ in range(4)]
+            nt = L.call("fea_conv_num_tiles", n, h, w)
+            part = torch.empty(nt * co * 2, device="cuda")
+            fn = lambda: L.call(entry, x, ci, wp, y, co, yb, co, *cf, part, n, h, w, ci, co, code, S)  # noqa: E731
         else:
             entry = a.entry or "fea_conv3x3_wgrad"
             dy = torch.randn(n, h, w, co, device="cuda", generator=g).to(dt)

@@ -138,6 +138,85 @@ def test_conv3x3_dgrad_with_fused_bn_backward_reduction(shape):
     assert rel_l2(got, ref) < 1e-5, f"fused BN-backward sums: {rel_l2(got, ref):.3e}"
 
 
+SHAPES_P = [  # N, H, W, Cin, Cout -- shapes the persistent kernels serve (H % 8 == 0, W % 32 == 0, channels 64 / 128)
+    (2, 32, 32, 64, 64),
+    (1, 8, 32, 64, 64),         # a single tile: every halo line is an image border
+    (3, 24, 96, 64, 64),        # odd tile counts: workgroups with different numbers of tiles
+    (2, 16, 64, 128, 64),       # two K chunks
+    (2, 16, 64, 64, 128),       # two column groups
+    (1, 40, 64, 128, 128),
+    (5, 64, 128, 64, 64),       # 320 tiles: more tiles than workgroups, several tiles per workgroup
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES_P)
+def test_persistent_conv3x3_fwd_stats_dgrad_and_bnred(shape):
+    """fea_conv3x3p / fea_conv3x3p_dgrad_bnred (conv_p.hip) against F.conv2d on bf16-rounded inputs and against the
+    plain entry points they replace on the shallow levels: same outputs to bf16 rounding of the same fp32 sums, same
+    BatchNorm partial sums, same fused BatchNorm-backward sums."""
+    n, h, w, ci, co = shape
+    dt = torch.bfloat16
+    code = L.dt_code(dt)
+    rows = L.call("fea_conv3x3p_rows", n, h, w, ci, co, code)
+    assert rows > 0
+    g = torch.Generator().manual_seed(31)
+    x = rnd(dt, n, ci, h, w, gen=g)
+    wt = (rnd(dt, co, ci, 3, 3, gen=g) / (3 * ci ** 0.5)).to(dt).float()
+    bias = torch.randn(co, generator=g)
+    ref = F.conv2d(x, wt, bias, padding=1)
+    xd = to_nhwc(x, dt, ld=ci + 64, off=64)
+    wp = torch.empty(9 * co * ci, dtype=dt, device=DEV)
+    L.call("fea_pack_conv3x3_frag", wt.to(DEV), wp, co, ci, 0, code, S())
+    ldy, off = co + 64, 64
+    y = torch.full((n, h, w, ldy), float("nan"), dtype=dt, device=DEV)
+    stats = torch.full((rows, co, 2), float("nan"), device=DEV)
+    L.call("fea_conv3x3p", view_ptr(xd, 64), ci + 64, wp, bias.to(DEV), view_ptr(y, off), ldy, stats, n, h, w, ci, co, code, S())
+    torch.cuda.synchronize()
+    check(from_nhwc(y, co, off), ref, dt, "persistent conv3x3 fwd")
+    assert torch.isnan(y[..., :off].float()).all(), "wrote outside its channel slice"
+    s = stats.double().sum(0).cpu()
+    ref_s = torch.stack([ref.double().sum((0, 2, 3)), (ref.double() ** 2).sum((0, 2, 3))], 1)
+    assert rel_l2(s, ref_s) < 1e-5, "BN partial sums"
+    # without bias / stats (plain data gradient), against the plain kernel bit for bit is not required (different
+    # summation order inside the MFMA chain is the same here: same k order) -- compare to the reference
+    dy = rnd(dt, n, co, h, w, gen=g)
+    ref_dx = F.conv_transpose2d(dy, wt, padding=1)
+    wpd = torch.empty(9 * co * ci, dtype=dt, device=DEV)
+    L.call("fea_pack_conv3x3_frag", wt.to(DEV), wpd, co, ci, 1, code, S())
+    dyd = to_nhwc(dy, dt)
+    dx = torch.full((n, h, w, ci), float("nan"), dtype=dt, device=DEV)
+    rows_d = L.call("fea_conv3x3p_rows", n, h, w, co, ci, code)
+    L.call("fea_conv3x3p", dyd, co, wpd, None, dx, ci, None, n, h, w, co, ci, code, S())
+    torch.cuda.synchronize()
+    check(from_nhwc(dx, ci), ref_dx, dt, "persistent conv3x3 dgrad")
+    # fused BatchNorm-backward reduction: da identical to the plain dgrad above, sums equal to fea_bn_relu_bwd_reduce's
+    yb = rnd(dt, n, ci, h, w, gen=g)
+    scale, shift = torch.randn(ci, generator=g), torch.randn(ci, generator=g)
+    mean, invstd = torch.randn(ci, generator=g), torch.rand(ci, generator=g) + 0.5
+    coef = [t.to(DEV) for t in (scale, shift, mean, invstd)]
+    ybd = to_nhwc(yb, dt)
+    nblk = L.call("fea_bn_bwd_blocks", n, h, w, ci)
+    part_ref = torch.zeros(nblk, ci, 2, device=DEV)
+    L.call("fea_bn_relu_bwd_reduce", dx, ci, None, ybd, *coef, part_ref, n, h, w, ci, code, S())
+    da = torch.full((n, h, w, ci), float("nan"), dtype=dt, device=DEV)
+    part = torch.full((rows_d, ci, 2), float("nan"), device=DEV)
+    L.call("fea_conv3x3p_dgrad_bnred", dyd, co, wpd, da, ci, ybd, ci, *coef, part, n, h, w, co, ci, code, S())
+    torch.cuda.synchronize()
+    assert torch.equal(da.view(torch.int16), dx.view(torch.int16)), "fused kernel changed the data gradient"
+    got, want = part.double().sum(0).cpu(), part_ref.double().sum(0).cpu()
+    assert rel_l2(got[:, 0], want[:, 0]) < 1e-5 and rel_l2(got[:, 1], want[:, 1]) < 1e-4, (rel_l2(got[:, 0], want[:, 0]), rel_l2(got[:, 1], want[:, 1]))
+
+
+def test_persistent_conv3x3_rejects_shapes_it_does_not_serve():
+    code = L.dt_code(torch.bfloat16)
+    assert L.call("fea_conv3x3p_rows", 1, 24, 40, 64, 64, code) == 0          # W % 32
+    assert L.call("fea_conv3x3p_rows", 1, 32, 32, 256, 128, code) == 0        # Cin
+    assert L.call("fea_conv3x3p_rows", 1, 32, 32, 64, 64, L.F32) == 0         # fp32
+    x = torch.zeros(64, device=DEV)
+    with pytest.raises(L.FeaError):
+        L.call("fea_conv3x3p", x, 64, x, None, x, 64, None, 1, 24, 40, 64, 64, code, S())
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64), (1, 16, 16, 128, 64), (1, 24, 40, 64, 128), (1, 8, 8, 64, 192)])
 def test_conv3x3_wgrad(dt, shape):
