@@ -64,6 +64,9 @@ SIGNATURES = {
     "fea_head_bwd_blocks": (I, [I, I, I]),
     "fea_head_bwd": (I, [P, P, I, P, P, I, P, I, I, I, I, I, I, P]),
     "fea_head_bwd_finalize": (I, [P, I, P, P, I, I, P]),
+    "fea_head_loss_supported": (I, [I, I, I]),
+    "fea_head_loss_sums": (I, [P, I, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "fea_head_loss_bwd": (I, [P, I, P, P, P, P, P, P, I, P, F, I, I, I, I, I, I, P]),
     "fea_bce_dice_sums": (I, [P, P, P, P, I, I, L, P]),
     "fea_loss_blocks": (I, [I, I, L]),
     "fea_bce_dice_sums_static": (I, [P, P, P, I, I, L, P]),
@@ -136,7 +139,7 @@ def call(name: str, *args):
     lib = load()
     fn = getattr(lib, name)
     conv = [ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a for a in args]
-    if PROFILE is not None and SIGNATURES[name][1] and SIGNATURES[name][1][-1] is P and not name.endswith(("_blocks", "_tiles", "_chunk", "_ksize", "_coeffs", "_rows")):
+    if PROFILE is not None and SIGNATURES[name][1] and SIGNATURES[name][1][-1] is P and not name.endswith(("_blocks", "_tiles", "_chunk", "_ksize", "_coeffs", "_rows", "_supported")):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*conv)
@@ -144,6 +147,6 @@ def call(name: str, *args):
         PROFILE.append((name, e0, e1, conv))
     else:
         rc = fn(*conv)
-    if SIGNATURES[name][0] is I and rc < 0 and not name.endswith(("_blocks", "_tiles", "_chunk", "_ksize", "_coeffs", "_rows")):
+    if SIGNATURES[name][0] is I and rc < 0 and not name.endswith(("_blocks", "_tiles", "_chunk", "_ksize", "_coeffs", "_rows", "_supported")):
         raise FeaError(f"{name} failed ({rc}): {lib.fea_last_error().decode()}")
     return rc

@@ -426,6 +426,194 @@ extern "C" int fea_bce_dice_sums(const float* logits, const uint8_t* target, dou
 }
 
 // ---------------------------------------------------------------------------
+// Head + loss fused (training loop): the logits never go to HBM.
+//   pass 1 (head_loss_sums_kernel): logits of 4 consecutive pixels in registers -> per-block (bce, p*t, p, t) sums per class
+//   pass 2 (head_loss_bwd_kernel):  logits recomputed, dlogits formed in registers from the finalized sums, then exactly
+//                                   head_bwd_kernel's work: da = W^T dl and the dW / db partials
+// Same arithmetic per element as head_fwd4_kernel + bce_dice_*_kernel + head_bwd_kernel (the sums are accumulated in a
+// different order).  Requires HW % 4 == 0, <= 8 classes, bf16 or fp32 activations.
+template <typename T>
+__global__ __launch_bounds__(256) void head_loss_sums_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const uint8_t* __restrict__ tgt,
+                                                             float* __restrict__ logits, float* __restrict__ part,
+                                                             long long nquad, long long HW, int Ccls) {
+    __shared__ float ws[8 * 64 + 8];
+    __shared__ float red[4][8][4];
+    for (int i = threadIdx.x; i < 8 * 64; i += 256) ws[i] = i < Ccls * 64 ? w[i] : 0.f;
+    if (threadIdx.x < 8) ws[8 * 64 + threadIdx.x] = threadIdx.x < Ccls ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const int sub = threadIdx.x & 7;
+    const float bsub = ws[8 * 64 + sub];
+    float sb = 0.f, si = 0.f, sp = 0.f, st = 0.f;
+    const long long stride = (long long)gridDim.x * 32;
+    for (long long q = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); q < nquad; q += stride) {
+        const long long p0 = q * 4;
+        float f[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load8<T>(a + (p0 + k) * lda + sub * 8, f[k]);
+        const long long n = p0 / HW, hw = p0 - n * HW;
+        uint32_t tw = 0;
+        if (sub < Ccls) tw = *reinterpret_cast<const uint32_t*>(tgt + (n * Ccls + sub) * HW + hw);
+        float v[8][4];
+        int woff = sub * 8;
+        asm volatile("" : "+v"(woff));
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float wr[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wr[j] = ws[c * 64 + woff + j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s_ = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s_ = __builtin_fmaf(f[k][j], wr[j], s_);
+                v[c][k] = s_;
+            }
+        }
+        float v4[4][4], v2[2][4], v1[4];
+        const bool b4 = sub & 4, b2 = sub & 2, b1 = sub & 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v4[c][k] = (b4 ? v[c + 4][k] : v[c][k]) + __shfl_xor(b4 ? v[c][k] : v[c + 4][k], 4);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v2[c][k] = (b2 ? v4[c + 2][k] : v4[c][k]) + __shfl_xor(b2 ? v4[c][k] : v4[c + 2][k], 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v1[k] = (b1 ? v2[1][k] : v2[0][k]) + __shfl_xor(b1 ? v2[0][k] : v2[1][k], 1);
+        if (sub < Ccls) {
+            const f32x4 o = {v1[0] + bsub, v1[1] + bsub, v1[2] + bsub, v1[3] + bsub};
+            if (logits) *reinterpret_cast<f32x4*>(logits + (n * Ccls + sub) * HW + hw) = o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) loss_terms(o[k], ((tw >> (8 * k)) & 0xff) ? 1.f : 0.f, sb, si, sp, st);
+        }
+    }
+    // lanes with equal sub hold the same class: sum them over the wave, then over the four waves
+    float vals[4] = {sb, si, sp, st};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float x = vals[k];
+        x += __shfl_xor(x, 8); x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+        if ((threadIdx.x & 63) < 8) red[threadIdx.x >> 6][sub][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < Ccls * 4) {
+        const int c = threadIdx.x >> 2, k = threadIdx.x & 3;
+        part[((long long)blockIdx.x * Ccls + c) * 4 + k] = red[0][c][k] + red[1][c][k] + red[2][c][k] + red[3][c][k];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_loss_bwd_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const uint8_t* __restrict__ tgt,
+                                                            const double* __restrict__ sums, float* __restrict__ loss,
+                                                            T* __restrict__ da, int ldda, float* __restrict__ part,
+                                                            float gscale, long long npix, long long HW, int N, int Ccls,
+                                                            long long pix_per_block) {
+    constexpr int NC = 8, PP = 2;                     // pixels per 8-lane group and iteration
+    __shared__ float ws[NC * 64 + NC];
+    __shared__ float cf[NC][2];                       // per class: 1/(S+1), (2I+1)/(S+1)
+    __shared__ float red[4][NC * 65];
+    for (int i = threadIdx.x; i < NC * 64; i += 256) ws[i] = i < Ccls * 64 ? w[i] : 0.f;
+    if (threadIdx.x < NC) {
+        const int c = threadIdx.x;
+        ws[NC * 64 + c] = c < Ccls ? bias[c] : 0.f;
+        const double I = c < Ccls ? sums[c * 4 + 1] : 0.0, S = c < Ccls ? sums[c * 4 + 2] + sums[c * 4 + 3] : 0.0;
+        cf[c][0] = (float)(1.0 / (S + 1.0));
+        cf[c][1] = (float)((2.0 * I + 1.0) / (S + 1.0));
+    }
+    const long long total = (long long)N * Ccls * HW;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss) {
+        double bce = 0.0, dice = 0.0;
+        for (int c = 0; c < Ccls; ++c) {
+            bce += sums[c * 4];
+            dice += (2.0 * sums[c * 4 + 1] + 1.0) / (sums[c * 4 + 2] + sums[c * 4 + 3] + 1.0);
+        }
+        loss[0] = (float)(bce / (double)total + 1.0 - dice / Ccls);
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 7;
+    const float itot = 1.f / (float)total, ic = 1.f / (float)Ccls;
+    float gw[NC][8], gb[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        gb[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gw[c][j] = 0.f;
+    }
+    const long long p_begin = (long long)blockIdx.x * pix_per_block;
+    const long long p_end = p_begin + pix_per_block < npix ? p_begin + pix_per_block : npix;
+    for (long long p0 = p_begin + (threadIdx.x >> 3) * PP; p0 < p_end; p0 += 32 * PP) {
+        const long long n = p0 / HW, hw = p0 - n * HW;
+        float f[PP][8], o[PP][8];
+#pragma unroll
+        for (int k = 0; k < PP; ++k) load8<T>(a + (p0 + k) * lda + sub * 8, f[k]);
+        int woff = sub * 8;
+        asm volatile("" : "+v"(woff));
+#pragma unroll
+        for (int k = 0; k < PP; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[k][j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c < Ccls) {                                  // (uniform)
+                const uint16_t tw = *reinterpret_cast<const uint16_t*>(tgt + (n * Ccls + c) * HW + hw);
+                float wr[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wr[j] = ws[c * 64 + woff + j];
+#pragma unroll
+                for (int k = 0; k < PP; ++k) {
+                    float s_ = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s_ = __builtin_fmaf(f[k][j], wr[j], s_);
+                    s_ += __shfl_xor(s_, 1); s_ += __shfl_xor(s_, 2); s_ += __shfl_xor(s_, 4);
+                    const float v = s_ + ws[NC * 64 + c];
+                    const float tt = ((tw >> (8 * k)) & 0xff) ? 1.f : 0.f;
+                    const float e = expf(-fabsf(v));
+                    const float r = 1.f / (1.f + e);
+                    const float pr = v >= 0.f ? r : e * r;
+                    const float ddice = (2.f * tt - cf[c][1]) * cf[c][0];
+                    const float d = ((pr - tt) * itot - ddice * pr * (1.f - pr) * ic) * gscale;
+                    gb[c] += d;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        o[k][j] = __builtin_fmaf(d, wr[j], o[k][j]);
+                        gw[c][j] = __builtin_fmaf(d, f[k][j], gw[c][j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PP; ++k) store8<T>(da + (p0 + k) * ldda + sub * 8, o[k]);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = gw[c][j];
+            v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            gw[c][j] = v;
+        }
+        float v = gb[c];
+        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        gb[c] = v;
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wv][c * 65 + sub * 8 + j] = gw[c][j];
+            if (sub == 0) red[wv][c * 65 + 64] = gb[c];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Ccls * 65; i += 256)
+        part[(long long)blockIdx.x * (Ccls * 65) + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+// ---------------------------------------------------------------------------
 // fea_bce_dice_sums for callers that cannot allocate (HIP graph capture, tight serving / evaluation
 // loops, harnesses that forbid hipMalloc): the per-block partial sums live in a fixed device array of
 // this code object instead of a caller workspace.  Every GPU holds its own copy of the array at its
@@ -497,6 +685,50 @@ extern "C" int fea_mask_iou(const float* logits, const uint8_t* target, uint8_t*
 extern "C" int fea_binarise(const uint8_t* grey, uint8_t* out, long long n, void* stream) {
     FEA_CHECK(grey && out && n > 0, FEA_E_BADARG, "fea_binarise: bad args");
     hipLaunchKernelGGL(binarise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grey, out, n);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+// ---- fused head + loss ---------------------------------------------------------------------
+extern "C" int fea_head_loss_supported(int H, int W, int Ccls) { return ((long long)H * W) % 4 == 0 && Ccls >= 1 && Ccls <= 8; }
+
+extern "C" int fea_head_loss_sums(const void* a, int lda, const float* w, const float* bias, const uint8_t* target,
+                                  float* logits, double* sums, float* part, int N, int H, int W, int Cin, int Ccls,
+                                  int dtype, void* stream) {
+    const char* who = "fea_head_loss_sums";
+    FEA_CHECK(a && w && bias && target && sums && part && N > 0 && H > 0 && W > 0, FEA_E_BADARG, "%s: bad args", who);
+    FEA_CHECK(Cin == 64 && lda >= 64 && lda % 8 == 0, FEA_E_UNSUPPORTED_SHAPE, "%s: Cin=%d lda=%d", who, Cin, lda);
+    FEA_CHECK(fea_head_loss_supported(H, W, Ccls), FEA_E_UNSUPPORTED_SHAPE, "%s: needs H*W %% 4 == 0 and 1..8 classes (use fea_head_fwd + fea_bce_dice_sums)", who);
+    FEA_CHECK((uintptr_t)target % 4 == 0 && (!logits || (uintptr_t)logits % 16 == 0), FEA_E_BADARG, "%s: alignment", who);
+    const long long npix = (long long)N * H * W, HW = (long long)H * W;
+    const int nblk = head_blocks(npix);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FEA_BF16) hipLaunchKernelGGL((head_loss_sums_kernel<__bf16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, logits, part, npix / 4, HW, Ccls);
+    else if (dtype == FEA_F32) hipLaunchKernelGGL((head_loss_sums_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)a, lda, w, bias, target, logits, part, npix / 4, HW, Ccls);
+    else { fea_set_error("%s: bad dtype", who); return FEA_E_BADARG; }
+    FEA_LAUNCH_CHECK();
+    // part[blk][class][4]: the layout bce_dice_sums_finalize_kernel reads with "N" = blocks and one chunk per plane
+    hipLaunchKernelGGL(bce_dice_sums_finalize_kernel, dim3(Ccls), dim3(256), 0, s, part, sums, nblk, Ccls, 1);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+extern "C" int fea_head_loss_bwd(const void* a, int lda, const float* w, const float* bias, const uint8_t* target,
+                                 const double* sums, float* loss, void* da, int ldda, float* part, float gscale,
+                                 int N, int H, int W, int Cin, int Ccls, int dtype, void* stream) {
+    const char* who = "fea_head_loss_bwd";
+    FEA_CHECK(a && w && bias && target && sums && da && part && N > 0 && H > 0 && W > 0, FEA_E_BADARG, "%s: bad args", who);
+    FEA_CHECK(Cin == 64 && lda >= 64 && lda % 8 == 0 && ldda >= 64 && ldda % 8 == 0, FEA_E_UNSUPPORTED_SHAPE, "%s: Cin=%d lda=%d ldda=%d", who, Cin, lda, ldda);
+    FEA_CHECK(fea_head_loss_supported(H, W, Ccls), FEA_E_UNSUPPORTED_SHAPE, "%s: needs H*W %% 4 == 0 and 1..8 classes", who);
+    FEA_CHECK((uintptr_t)target % 4 == 0, FEA_E_BADARG, "%s: alignment", who);
+    const long long npix = (long long)N * H * W, HW = (long long)H * W;
+    const int nblk = head_blocks(npix);
+    long long ppb = (npix + nblk - 1) / nblk;
+    ppb = (ppb + 63) / 64 * 64;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FEA_BF16) hipLaunchKernelGGL((head_loss_bwd_kernel<__bf16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, npix, HW, N, Ccls, ppb);
+    else if (dtype == FEA_F32) hipLaunchKernelGGL((head_loss_bwd_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)a, lda, w, bias, target, sums, loss, (float*)da, ldda, part, gscale, npix, HW, N, Ccls, ppb);
+    else { fea_set_error("%s: bad dtype", who); return FEA_E_BADARG; }
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }

@@ -398,7 +398,9 @@ class UNetEngine:
         return self._pack(name + ("/b" if bwd else "/f"), p, p.numel(), "fea_pack_upconv2x2", ci, co, bwd)
 
     # -------------------------------------------------------------- forward
-    def forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, training: bool, head: bool = True) -> Optional[torch.Tensor]:
+        """`head=False` (training loops that use the fused head + loss kernels, see backward(target=...)): stop after
+        dec1; the logits are formed inside the loss kernels and never stored."""
         if not x.is_cuda:
             raise L.FeaError("fea_amd runs on a ROCm device only (no CPU fallback): move the module and input to 'cuda'")
         if x.dim() != 4 or x.shape[1] != self.in_channels:
@@ -525,14 +527,15 @@ class UNetEngine:
             conv_bn(f"{blk}.0", pl.cat[k], 2 * c, 2 * c, h, w, c, pl.a0[blk], c, None)
             conv_bn(f"{blk}.3", pl.a0[blk], c, c, h, w, c, pl.a3[blk], c, None)
             d, cd = pl.a3[blk], c
-        L.call("fea_head_fwd", d, 64, P["out.weight"], P["out.bias"], pl.logits, N, H, W, 64, self.num_classes, code, S)
+        if head:
+            L.call("fea_head_fwd", d, 64, P["out.weight"], P["out.bias"], pl.logits, N, H, W, 64, self.num_classes, code, S)
         if training:
             torch._foreach_add_([B[f"{b}.{i}.num_batches_tracked"] for b in BLOCKS for i in (1, 4)], 1)
         if taps is not None:
             self._export_taps(pl, taps)
         pl.training = training
         self._last = (pl, training)
-        return pl.logits
+        return pl.logits if head else None
 
     def _export_taps(self, pl: _Plan, taps: dict):
         """Debug/test hook: activated outputs (NCHW fp32) of every conv layer."""
@@ -548,10 +551,16 @@ class UNetEngine:
                 taps[f"{blk}.3.act"] = pl.a3[blk].float().permute(0, 3, 1, 2).contiguous()
 
     # -------------------------------------------------------------- backward
-    def backward(self, dlogits: torch.Tensor, plan: Optional[_Plan] = None) -> Dict[str, torch.Tensor]:
+    def fused_loss_supported(self, H: int, W: int) -> bool:
+        return bool(L.call("fea_head_loss_supported", H, W, self.num_classes))
+
+    def backward(self, dlogits: Optional[torch.Tensor], plan: Optional[_Plan] = None,
+                 target: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Gradients of every parameter for upstream gradient `dlogits`
         ([N,classes,H,W] fp32).  Returns views into the flat gradient buffer.
-        `plan`: the plan of the forward this is the backward of (default: the last forward)."""
+        `plan`: the plan of the forward this is the backward of (default: the last forward).
+        `target` (uint8 [N,classes,H,W]) with dlogits=None: the upstream is the BCE+Dice loss of the logits against
+        `target`; head, loss and their backward run fused (fea_head_loss_sums / _bwd), the loss lands in `plan.loss`."""
         pl, training = self._last if plan is None else (plan, plan.training)
         if not training:
             raise L.FeaError("backward through eval-mode BatchNorm is not supported (the reference trains in train() mode)")
@@ -567,7 +576,9 @@ class UNetEngine:
         S = L.stream_ptr()
         code = self.code
         g = self.grad_views
-        dl = dlogits.detach().contiguous().float()
+        dl = dlogits.detach().contiguous().float() if dlogits is not None else None
+        if dl is None and target is None:
+            raise L.FeaError("backward needs dlogits or a loss target")
         es = torch.empty(0, dtype=self.dtype).element_size()
 
         def off_ptr(t, ch_off):
@@ -680,7 +691,20 @@ class UNetEngine:
 
         # head
         nblk = L.call("fea_head_bwd_blocks", N, H, W)
-        L.call("fea_head_bwd", dl, pl.a3["dec1"], 64, P["out.weight"], pl.G[0], 64, pl.head_part, N, H, W, 64, self.num_classes, code, S)
+        if dl is None:
+            tg = target.contiguous()
+            if tg.dtype != torch.uint8 or tuple(tg.shape) != (N, self.num_classes, H, W):
+                raise L.FeaError(f"target must be uint8 [{N},{self.num_classes},{H},{W}]")
+            if getattr(pl, "loss_sums", None) is None:
+                pl.loss_sums = torch.empty((self.num_classes, 4), dtype=torch.float64, device=self.device)
+                pl.loss_part = torch.empty(nblk * self.num_classes * 4, dtype=torch.float32, device=self.device)
+                pl.loss = torch.empty(1, dtype=torch.float32, device=self.device)
+            L.call("fea_head_loss_sums", pl.a3["dec1"], 64, P["out.weight"], P["out.bias"], tg, None, pl.loss_sums, pl.loss_part,
+                   N, H, W, 64, self.num_classes, code, S)
+            L.call("fea_head_loss_bwd", pl.a3["dec1"], 64, P["out.weight"], P["out.bias"], tg, pl.loss_sums, pl.loss,
+                   pl.G[0], 64, pl.head_part, 1.0, N, H, W, 64, self.num_classes, code, S)
+        else:
+            L.call("fea_head_bwd", dl, pl.a3["dec1"], 64, P["out.weight"], pl.G[0], 64, pl.head_part, N, H, W, 64, self.num_classes, code, S)
         L.call("fea_head_bwd_finalize", pl.head_part, nblk, g["out.weight"], g["out.bias"], 64, self.num_classes, S)
         done("out.weight", "out.bias")
         # decoder

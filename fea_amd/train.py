@@ -109,6 +109,10 @@ class UNetTrainer:
             raise ValueError(f"optimizer must be 'hip' or 'torch', got {cfg['optimizer']!r}")
         self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=cfg["num_epochs"], eta_min=1e-6)
         self.loss_ws = {}
+        # Fused head + loss kernels (fea_head_loss_sums / _bwd: logits and dlogits stay in registers, 2 GB less HBM
+        # traffic per batch-64 step) are correct but SLOWER than the four separate kernels on MI355X (3.05 ms vs
+        # 2.3 ms per step: they are latency-bound) -- opt-in until that is fixed.
+        self.fuse_head_loss = os.environ.get("FEA_AMD_FUSE_HEAD_LOSS", "0") == "1"
         self.buckets = None
         self.distributed = distributed
         self._grads_bound = False
@@ -126,12 +130,19 @@ class UNetTrainer:
         """One optimisation step; returns the loss as a 1-element device tensor."""
         m = self.model
         m.train()
-        logits = self.eng.forward(x, True)
-        loss, dl = Fn.bce_dice_loss_and_grad(logits, target_u8, ws=self.loss_ws)
+        fused = self.fuse_head_loss and self.eng.fused_loss_supported(x.shape[2], x.shape[3])
+        logits = self.eng.forward(x, True, head=not fused)
         if not self._grads_bound:
             self.eng._ensure_device(x)
             self._bind_grads()
-        self.eng.backward(dl)                     # writes p.grad (views of the flat buffer)
+        if fused:
+            # head + BCE/Dice + their backward fused: the logits never go to HBM (writes p.grad: views of the flat buffer)
+            self.eng.backward(None, target=target_u8)
+            loss = self.eng._last[0].loss.clone()      # the plan's scalar is rewritten by the next step
+        else:
+            loss, dl = Fn.bce_dice_loss_and_grad(logits, target_u8, ws=self.loss_ws)
+            loss = loss.clone()
+            self.eng.backward(dl)
         if self.buckets is not None:
             self.buckets.wait()
         if isinstance(self.opt, ClipAdamW):

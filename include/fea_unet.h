@@ -247,6 +247,21 @@ int fea_bce_dice_grad(const float* logits, const uint8_t* target, const double* 
 /* mask = logits > 0 (nullable out); inter/union int64[Ccls] are ACCUMULATED (caller zeroes). */
 int fea_mask_iou(const float* logits, const uint8_t* target, uint8_t* mask, long long* inter, long long* uni,
                  int N, int Ccls, long long HW, void* stream);
+/* Head + loss fused for training loops: the logits and their gradient stay in registers.
+ *   fea_head_loss_sums: logits = out.weight . a + bias (models.py:23,46) formed per pixel, (sum bce, sum p*t, sum p,
+ *     sum t) per class -> sums[Ccls][4] (fp64) as fea_bce_dice_sums gives them; logits (nullable) are stored only on
+ *     request.  part: fp32 workspace of fea_head_bwd_blocks(N,H,W) * Ccls * 4 elements.
+ *   fea_head_loss_bwd: recomputes the logits, forms dlogits = d loss / d logits * gscale from `sums` in registers, and
+ *     does fea_head_bwd's work: da = W^T dlogits and part[nblk][Ccls*65] for fea_head_bwd_finalize; loss[0] (nullable)
+ *     = BCE(mean) + 1 - mean_c dice_c.
+ * Need H*W % 4 == 0 and Ccls <= 8 (fea_head_loss_supported); otherwise use the separate entry points. */
+int fea_head_loss_supported(int H, int W, int Ccls);
+int fea_head_loss_sums(const void* a, int lda, const float* w, const float* bias, const uint8_t* target,
+                       float* logits, double* sums, float* part, int N, int H, int W, int Cin, int Ccls,
+                       int dtype, void* stream);
+int fea_head_loss_bwd(const void* a, int lda, const float* w, const float* bias, const uint8_t* target,
+                      const double* sums, float* loss, void* da, int ldda, float* part, float gscale,
+                      int N, int H, int W, int Cin, int Ccls, int dtype, void* stream);
 /* target = grey > 127 */
 int fea_binarise(const uint8_t* grey, uint8_t* out, long long n, void* stream);
 

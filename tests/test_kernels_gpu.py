@@ -523,6 +523,61 @@ def test_head_forward_backward(dt, ncls):
     assert rel_l2(db.cpu(), br.grad) < 1e-5
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 6, 24, 40), (1, 1, 16, 16), (3, 8, 32, 36), (2, 3, 6, 6)])
+def test_fused_head_loss_matches_the_separate_kernels(dt, shape):
+    """fea_head_loss_sums / fea_head_loss_bwd (logits and dlogits kept in registers) against the chain they replace:
+    fea_head_fwd -> fea_bce_dice_sums -> fea_bce_dice_grad -> fea_head_bwd (+ finalize), and against the oracle's loss."""
+    from oracle import unet_oracle as O
+    n, c, h, w = shape
+    code = L.dt_code(dt)
+    g = torch.Generator().manual_seed(8)
+    a = rnd(dt, n, 64, h, w, gen=g)
+    wt = torch.randn(c, 64, generator=g) / 4
+    bias = torch.randn(c, generator=g)
+    tgt = (torch.rand(n, c, h, w, generator=g) < 0.2).to(torch.uint8)
+    assert L.call("fea_head_loss_supported", h, w, c) == 1
+    ad, wd, bd, td = to_nhwc(a, dt, ld=72, off=8), wt.to(DEV), bias.to(DEV), tgt.to(DEV)
+    ap = view_ptr(ad, 8)
+    # separate kernels
+    logits = torch.empty(n, c, h, w, device=DEV)
+    L.call("fea_head_fwd", ap, 72, wd, bd, logits, n, h, w, 64, c, code, S())
+    part = torch.empty(L.call("fea_loss_blocks", n, c, h * w) * 4, device=DEV)
+    sums = torch.empty(c, 4, dtype=torch.float64, device=DEV)
+    loss = torch.empty(1, device=DEV)
+    dl = torch.empty_like(logits)
+    L.call("fea_bce_dice_sums", logits, td, sums, part, n, c, h * w, S())
+    L.call("fea_bce_dice_grad", logits, td, sums, loss, dl, 1.0, n, c, h * w, S())
+    nblk = L.call("fea_head_bwd_blocks", n, h, w)
+    hpart = torch.empty(nblk * c * 65, device=DEV)
+    da = torch.full((n, h, w, 64), float("nan"), dtype=dt, device=DEV)
+    dW, db = torch.empty(c, 64, device=DEV), torch.empty(c, device=DEV)
+    L.call("fea_head_bwd", dl, ap, 72, wd, da, 64, hpart, n, h, w, 64, c, code, S())
+    L.call("fea_head_bwd_finalize", hpart, nblk, dW, db, 64, c, S())
+    # fused
+    lg2 = torch.full((n, c, h, w), float("nan"), device=DEV)
+    sums2 = torch.empty(c, 4, dtype=torch.float64, device=DEV)
+    part2 = torch.empty(nblk * c * 4, device=DEV)
+    loss2 = torch.empty(1, device=DEV)
+    hpart2 = torch.empty(nblk * c * 65, device=DEV)
+    da2 = torch.full((n, h, w, 80), float("nan"), dtype=dt, device=DEV)
+    dW2, db2 = torch.empty(c, 64, device=DEV), torch.empty(c, device=DEV)
+    L.call("fea_head_loss_sums", ap, 72, wd, bd, td, lg2, sums2, part2, n, h, w, 64, c, code, S())
+    L.call("fea_head_loss_bwd", ap, 72, wd, bd, td, sums2, loss2, view_ptr(da2, 16), 80, hpart2, 1.0, n, h, w, 64, c, code, S())
+    L.call("fea_head_bwd_finalize", hpart2, nblk, dW2, db2, 64, c, S())
+    torch.cuda.synchronize()
+    if dt == torch.bfloat16:          # same kernel structure as fea_head_fwd's bf16 path: identical bits
+        assert torch.equal(lg2, logits), "the fused kernel's logits differ from fea_head_fwd's"
+    assert rel_l2(lg2.cpu(), logits.cpu()) < 1e-6
+    assert rel_l2(sums2.cpu(), sums.cpu()) < 1e-6
+    assert abs(loss2.item() - loss.item()) < 1e-6 * abs(loss.item())
+    ref_loss = O.bce_dice_loss(logits.cpu(), tgt)
+    assert abs(loss2.item() - ref_loss.item()) < 1e-5 * abs(ref_loss.item())
+    check(da2[..., 16:80], from_nhwc(da, 64).permute(0, 2, 3, 1), dt, "fused head backward: da")
+    assert torch.isnan(da2[..., :16].float()).all()
+    assert rel_l2(dW2.cpu(), dW.cpu()) < 1e-5 and rel_l2(db2.cpu(), db.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(2, 6, 32, 48), (1, 1, 16, 16), (3, 6, 128, 96), (2, 3, 5, 7)])
 def test_loss_mask_iou(shape):
     """BCE+Dice loss and its gradient within fp32 tolerance; mask and IoU

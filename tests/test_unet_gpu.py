@@ -208,10 +208,13 @@ def test_config1_eval_forward_matches_reference():
     assert abs(int(mask.sum()) - case["pred_sum"]) <= 4
 
 
-def test_training_steps_track_the_oracle():
-    """Three optimizer steps (fwd, BCE+Dice, bwd, clip 1.0, AdamW) in fp32."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_training_steps_track_the_oracle(fused):
+    """Three optimizer steps (fwd, BCE+Dice, bwd, clip 1.0, AdamW) in fp32; with the head, the loss and their backward
+    as four kernels, and fused into two (fea_head_loss_sums / fea_head_loss_bwd)."""
     m, params, bufs = make(12, "fp32")
     tr = UNetTrainer(m)
+    tr.fuse_head_loss = fused
     x, tgt = O.synthetic_batch(2, 32, 32, seed=99)
     g = torch.Generator().manual_seed(3)
     x = x + 0.1 * torch.randn(x.shape, generator=g)
