@@ -344,7 +344,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const T* __restrict__ 
     // UN items per iteration: all loads of the batch are issued before the first use
     // (memory-level parallelism; the loop is otherwise one dependent round trip per item)
     constexpr int NP = POOL ? 4 : 1;
-    constexpr int UN = POOL ? 1 : (APPLY ? 2 : 4);
+#ifndef BN_APPLY_UN
+#define BN_APPLY_UN 2
+#endif
+    constexpr int UN = POOL ? 1 : (APPLY ? BN_APPLY_UN : 4);
     for (long long itb = it0 + slot; itb < it1; itb += (long long)slots * UN) {
         u32x4 ry[UN][NP], rg[UN][NP], rp[UN];
         long long pidx[UN][NP];

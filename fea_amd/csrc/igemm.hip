@@ -31,6 +31,10 @@
 // dgrad), nn.ConvTranspose2d(ci,co,2,stride=2) models.py:15-21 (fwd, bwd-data).
 #include "common.h"
 
+#ifndef EPI2_GRP
+#define EPI2_GRP 4          // y loads in flight per thread in the fused BatchNorm-backward epilogue
+#endif
+
 struct IgemmArgs {
     const void* x; const void* w; const float* bias; void* y; float* stats;
     long long x_img_stride, y_img_stride;   // elements per image
@@ -618,7 +622,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
                 a0[j] = 0.f; a1[j] = 0.f;
             }
             const T* __restrict__ yb = (const T*)g.ybn + (long long)n_img * H * W * g.ldybn + cout0 + c * 8;
-            constexpr int GRP = 4;                    // y loads in flight per thread
+            // all y loads of the thread in flight at once (the accumulators are dead: 64 registers are free)
+            constexpr int GRP = EPI2_GRP < CPR ? EPI2_GRP : CPR;
 #pragma unroll
             for (int i0 = 0; i0 < CPR; i0 += GRP) {
                 u32x4 yv[GRP]; int pixv[GRP]; bool okv[GRP];

@@ -41,9 +41,13 @@ def main():
         ms = sum(prof[i + r * per_step][1].elapsed_time(prof[i + r * per_step][2]) for r in range(a.reps)) / a.reps
         ints = [v for v in args if isinstance(v, int) and 0 < v < (1 << 24)]
         desc, fl = "", 0.0
-        if name in ("fea_conv3x3", "fea_conv1x1"):
+        if name in ("fea_conv3x3", "fea_conv1x1", "fea_conv3x3p"):
             n, h, w, cin, cout = args[7:12]
-            fl = 2.0 * n * h * w * cin * cout * (9 if name == "fea_conv3x3" else 1)
+            fl = 2.0 * n * h * w * cin * cout * (1 if name == "fea_conv1x1" else 9)
+            desc = f"N{n} {h}x{w} {cin}->{cout}"
+        elif name in ("fea_conv3x3_dgrad_bnred", "fea_conv3x3p_dgrad_bnred"):
+            n, h, w, cin, cout = args[12:17]
+            fl = 2.0 * n * h * w * cin * cout * 9
             desc = f"N{n} {h}x{w} {cin}->{cout}"
         elif name == "fea_conv3x3_wgrad":
             n, h, w, cin, cout = args[7:12]
