@@ -31,28 +31,27 @@ from .models import FloorPlanSegmentationModel
 HALO = 96            # >= receptive-field radius 92, multiple of 16
 
 
-def window_plan(H: int, W: int, core: int, halo: int = HALO) -> Tuple[int, List[Tuple[int, int, int, int, int, int]]]:
-    """Windows covering an H x W image.  Returns (win, [(wy, wx, cy0, cy1, cx0, cx1)]):
-    a window is the win x win crop at (wy, wx); it owns the core rectangle
-    [cy0,cy1) x [cx0,cx1) (image coordinates).  Cores partition the image; every core
-    pixel is >= halo away from each window edge that is not an image edge."""
-    if H % 16 or W % 16 or core % 16 or halo % 16:
+def window_plan(H: int, W: int, core, halo: int = HALO) -> Tuple[int, int, List[Tuple[int, int, int, int, int, int]]]:
+    """Windows covering an H x W image.  `core` is an int or (core_h, core_w).  Returns
+    (win_h, win_w, [(wy, wx, cy0, cy1, cx0, cx1)]): a window is the win_h x win_w crop at (wy, wx); it owns the core
+    rectangle [cy0,cy1) x [cx0,cx1) (image coordinates).  Cores partition the image; every core pixel is >= halo away
+    from each window edge that is not an image edge.  A direction in which core + 2*halo covers the image is not cut:
+    (1024, 2048) cuts a 2048 x 2048 image into two 1216 x 2048 windows (19 % extra pixels instead of 41 % for four
+    1216 x 1216 windows)."""
+    ch, cw = (core, core) if isinstance(core, int) else core
+    if H % 16 or W % 16 or ch % 16 or cw % 16 or halo % 16:
         raise ValueError("H, W, core and halo must be multiples of 16")
-    win = core + 2 * halo
-    wh, ww = min(win, H), min(win, W)
-    if wh == H and ww == W:
-        return max(H, W) if H == W else -1, [(0, 0, 0, H, 0, W)]      # the image is one window (win = -1: not square)
-    if wh != ww:
-        raise ValueError(f"image {H}x{W} is smaller than the {win}-pixel window in one direction only; use a smaller core")
+    wh = H if ch + 2 * halo >= H else ch + 2 * halo
+    ww = W if cw + 2 * halo >= W else cw + 2 * halo
+    ys = [(0, H)] if wh == H else [(c0, min(H, c0 + ch)) for c0 in range(0, H, ch)]
+    xs = [(0, W)] if ww == W else [(c0, min(W, c0 + cw)) for c0 in range(0, W, cw)]
     out = []
-    for cy0 in range(0, H, core):
-        cy1 = min(H, cy0 + core)
+    for cy0, cy1 in ys:
         wy = min(max(cy0 - halo, 0), H - wh)
-        for cx0 in range(0, W, core):
-            cx1 = min(W, cx0 + core)
+        for cx0, cx1 in xs:
             wx = min(max(cx0 - halo, 0), W - ww)
             out.append((wy, wx, cy0, cy1, cx0, cx1))
-    return wh, out
+    return wh, ww, out
 
 
 def reduce_counts(inter: torch.Tensor, union: torch.Tensor, group=None):
@@ -70,7 +69,7 @@ class TiledSegmenter:
     (core + 2*halo)^2 pixels for core^2 useful ones: core 1024 (1.41x) runs 2048x2048 images
     45 % faster than core 512 (1.89x) on one MI355X (scripts/bench_infer.py)."""
 
-    def __init__(self, model: FloorPlanSegmentationModel, core: int = 1024, halo: int = HALO, window_batch: int = 4):
+    def __init__(self, model: FloorPlanSegmentationModel, core=1024, halo: int = HALO, window_batch: int = 4):
         self.model = model.eval()
         self.core, self.halo, self.window_batch = core, halo, window_batch
 
@@ -78,14 +77,14 @@ class TiledSegmenter:
     def logits(self, x: torch.Tensor) -> torch.Tensor:
         """x [N,C,H,W] on the device -> stitched logits [N,classes,H,W] fp32."""
         n, _, H, W = x.shape
-        win, plan = window_plan(H, W, self.core, self.halo)
+        wh, ww, plan = window_plan(H, W, self.core, self.halo)
         if len(plan) == 1:
             return self.model(x)
         out = torch.empty((n, self.model.num_classes, H, W), dtype=torch.float32, device=x.device)
         jobs = [(i,) + p for i in range(n) for p in plan]
         for b0 in range(0, len(jobs), self.window_batch):
             chunk = jobs[b0:b0 + self.window_batch]
-            crops = torch.stack([x[i, :, wy:wy + win, wx:wx + win] for (i, wy, wx, *_r) in chunk])
+            crops = torch.stack([x[i, :, wy:wy + wh, wx:wx + ww] for (i, wy, wx, *_r) in chunk])
             lg = self.model(crops.contiguous())
             for k, (i, wy, wx, cy0, cy1, cx0, cx1) in enumerate(chunk):
                 out[i, :, cy0:cy1, cx0:cx1] = lg[k, :, cy0 - wy:cy1 - wy, cx0 - wx:cx1 - wx]

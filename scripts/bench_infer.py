@@ -44,11 +44,14 @@ def main():
         del x
         big = torch.randn(2, 3, 2048, 2048, device="cuda")
         tgt = (torch.rand(2, 6, 2048, 2048, device="cuda") < 0.1).to(torch.uint8)
-        for core, wb in ((512, 16), (1024, 4)):
+        from fea_amd.inference import window_plan
+        for core, wb in ((512, 16), (1024, 4), ((1024, 2048), 2)):
             seg = TiledSegmenter(m, core=core, window_batch=wb)
             ms = timed(lambda: seg.segment(big, tgt), 3)
+            wh, ww, plan = window_plan(2048, 2048, core)
             out[f"tiled2048_core{core}"] = {"ms_per_image": ms / 2, "images_per_s": 2e3 / ms, "useful_tflops": 2 * 16 * GF512 / ms,
-                                            "windows_per_image": (2048 // core) ** 2, "window": core + 192}
+                                            "windows_per_image": len(plan), "window": [wh, ww],
+                                            "computed_over_useful_pixels": len(plan) * wh * ww / 2048.0 ** 2}
     print(json.dumps({"metric": "UNet inference throughput bf16", "data": "synthetic", **out}))
 
 

@@ -148,3 +148,26 @@ def test_cosine_lr_matches_torch():
         assert abs(opt.param_groups[0]["lr"] - O.cosine_lr(1e-4, e, 50)) < 1e-12
         opt.step()
         sch.step()
+
+
+def test_config1_on_a_real_floor_plan_matches_the_reference():
+    """BASELINE configs[0] as worded: the reference UNet, fp32 eval, batch 1, 256x256, on an image of the reference's
+    floor_plans2/ (tests/golden/config1_real.*, made by oracle/make_golden_config1_real.py from the reference module
+    and Pillow).  Pins both oracles on real data: the input-pipeline restatement bit for bit, the UNet to 1e-4."""
+    import json
+    import os
+    import numpy as np
+    from oracle import preprocess_oracle as P
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rec = json.load(open(os.path.join(gdir, "config1_real.json")))
+    data = np.load(os.path.join(gdir, "config1_real.npz"))
+    assert list(data["image"].shape) == rec["image_shape"]
+    small = P.resize_bilinear_u8(data["image"], rec["h"], rec["w"])
+    assert np.array_equal(small, data["resized"])                    # == Pillow's output, bit for bit
+    x = torch.from_numpy(P.to_tensor_normalize(small)).unsqueeze(0)
+    assert digest_err(rec["x"], x) < 1e-7
+    params, bufs = O.split_state(O.init_state_dict(rec["seed"]))
+    with torch.no_grad():
+        y, _ = O.forward(params, bufs, x, training=False)
+    assert digest_err(rec["logits"], y) < TOL
+    assert abs(int((y > 0).sum()) - rec["pred_sum"]) <= 4

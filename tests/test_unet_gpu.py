@@ -208,6 +208,28 @@ def test_config1_eval_forward_matches_reference():
     assert abs(int(mask.sum()) - case["pred_sum"]) <= 4
 
 
+def test_config1_on_a_real_floor_plan_image():
+    """BASELINE configs[0] on a shipped floor plan (fixture tests/golden/config1_real.npz: the decoded 525 x 800 image):
+    GPU input pipeline (resize to 256 + ToTensor + Normalize, bit-exact) -> HIP UNet fp32 eval -> logits against the
+    digest of the REFERENCE module's logits for the same file (oracle/make_golden_config1_real.py)."""
+    import json
+    import os
+    import numpy as np
+    from fea_amd.data import ImagePreprocessor
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rec = json.load(open(os.path.join(gdir, "config1_real.json")))
+    data = np.load(os.path.join(gdir, "config1_real.npz"))
+    pre = ImagePreprocessor(rec["h"])
+    x = pre.image(torch.from_numpy(data["image"])).unsqueeze(0)
+    assert digest_err(rec["x"], x.cpu()) < 1e-7
+    torch.manual_seed(rec["seed"])
+    m = fea_amd.FloorPlanSegmentationModel(compute_dtype="fp32").cuda().eval()
+    with torch.no_grad():
+        y = m(x)
+    assert digest_err(rec["logits"], y.cpu()) < 1e-4
+    assert abs(int((y > 0).sum()) - rec["pred_sum"]) <= 4
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_training_steps_track_the_oracle(fused):
     """Three optimizer steps (fwd, BCE+Dice, bwd, clip 1.0, AdamW) in fp32; with the head, the loss and their backward
@@ -590,6 +612,8 @@ def test_config5_tiled_2048_inference_and_iou():
     b = TiledSegmenter(m, core=512, window_batch=8).logits(x)
     assert a.shape == (1, 6, 2048, 2048) and torch.isfinite(a).all()
     assert rel_l2(a, b) < 2e-2, rel_l2(a, b)
+    c = TiledSegmenter(m, core=(1024, 2048), window_batch=2).logits(x)     # two 1216 x 2048 windows
+    assert rel_l2(c, a) < 2e-2, rel_l2(c, a)
     mask, inter, union = TiledSegmenter(m, core=1024, window_batch=2).segment(x, tgt)
     pm, pi, pu = O.mask_iou_counts(a.cpu(), tgt.cpu())
     assert torch.equal(mask.cpu(), pm) and torch.equal(inter.cpu(), pi) and torch.equal(union.cpu(), pu)
