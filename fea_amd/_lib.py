@@ -39,6 +39,7 @@ SIGNATURES = {
     "fea_conv3x3p_rows": (I, [I, I, I, I, I, I]),
     "fea_conv3x3p": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
     "fea_conv3x3p_dgrad_bnred": (I, [P, I, P, P, I, P, I, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "fea_conv3x3p_bias_relu": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "fea_conv3x3_bias_relu": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "fea_conv3x3_first_bias_relu": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "fea_conv1x1": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),

@@ -42,6 +42,8 @@ struct C3pArgs {
     const __bf16* ybn; int ldybn; long long ybn_img_stride;
     const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
     float* red_part;
+    // EPI 3: optional 2x2 max-pool of the activated output, [N][H/2][W/2] pixels ldpool apart
+    __bf16* pool; int ldpool; long long pool_img_stride;
     unsigned long long* dbg;                  // C3P_STAMPS builds only: per-workgroup phase cycle sums
 };
 
@@ -60,6 +62,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 // EPI 0: y = conv + bias (bias nullable); STATS 2: BatchNorm partial sums (sum y, sum y^2), STATS 1: sum y only (slot 1
 //        is written as 0: the ConvTranspose2d bias gradient taken from a data-gradient launch), STATS 0: none
 // EPI 2: da = conv (no bias) + fused first pass of the next BatchNorm backward (sum g, sum g*xhat)
+// EPI 3: inference with BatchNorm folded into weights and bias: relu(conv + bias), plus its MaxPool2d(2) when g.pool is set
 template <int NCH, int EPI, int STATS>
 __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     constexpr int YB = EPI == 2 ? 4 * 8192 : 0;        // per-wave private y tiles (128 px x 64 B)
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     // bias of the 64-column group in LDS (after the stages): read back as the C operand of a tile's first MFMAs, so
     // it occupies registers only for the first k-step of each tile
     float* const blds = reinterpret_cast<float*>(smem + 2 * P_STAGE + YB);
-    if (tid < 64) blds[tid] = (EPI == 0 && g.bias) ? g.bias[half * 64 + tid] : 0.f;
+    if (tid < 64) blds[tid] = ((EPI == 0 || EPI == 3) && g.bias) ? g.bias[half * 64 + tid] : 0.f;
     __syncthreads();
     f32x4 S[2], Q[2];                 // EPI 0: sum y, sum y^2 of channels cbase + 16 n + 4 q + e
     float a0[8], a1[8], csc[8], csh[8];   // EPI 2: channels cbase + chl + j
@@ -267,6 +270,41 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
         STAMP(2);
         if constexpr (C == NCH - 1) {
             __bf16* yt = g.y + (long long)ni * g.y_img_stride + ((long long)(ty * P_TH) * W + tx * P_TW) * g.ldy + y_lane;
+            if constexpr (EPI == 3) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[m][n][e] = fmaxf(acc[m][n][e], 0.f);
+                if (g.pool) {
+                    // window rows = accumulator tiles m and m + 2 of this lane, window columns = lanes r16 and r16 ^ 1;
+                    // the even lane of a pair stores the pooled pixel (tile row wm*2 + (m>>2), x = (m&1)*8 + r16/2)
+                    __bf16* pt = g.pool + (long long)ni * g.pool_img_stride +
+                                 ((long long)(ty * (P_TH / 2) + wm * 2) * (W / 2) + tx * (P_TW / 2) + (r16 >> 1)) * g.ldpool + cbase + chl;
+#pragma unroll
+                    for (int mp = 0; mp < 4; ++mp) {
+                        const int m = (mp & 1) + (mp >> 1) * 4;            // 0, 1, 4, 5
+                        uint32_t pk[2][2];
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float a = fmaxf(acc[m][n][e], acc[m + 2][n][e]);
+                                const float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xf, 0xf, false));
+                                v[e] = fmaxf(a, b);
+                            }
+                            pk[n][0] = pack_bf16x2(v[0], v[1]); pk[n][1] = pack_bf16x2(v[2], v[3]);
+                        }
+                        const auto r0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                        const u32x4 po = {r0[0], r1[0], r0[1], r1[1]};
+                        if ((r16 & 1) == 0)
+                            *reinterpret_cast<u32x4*>(pt + ((long long)(mp >> 1) * (W / 2) + (mp & 1) * 8) * g.ldpool) = po;
+                    }
+                }
+            }
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 if constexpr (EPI == 0 && STATS >= 1) {
@@ -434,6 +472,25 @@ extern "C" int fea_conv3x3p_dgrad_bnred(const void* dy, int lddy, const void* w_
     dim3 grid((unsigned)(p.npixwg * p.nhalf)), block(256);
     if (Cin == 64) hipLaunchKernelGGL((c3p_kernel<1, 2, 0>), grid, block, 0, (hipStream_t)stream, a);
     else           hipLaunchKernelGGL((c3p_kernel<2, 2, 0>), grid, block, 0, (hipStream_t)stream, a);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+// Eval-mode inference with BatchNorm folded into the packed weights and the bias (see fea_conv3x3_bias_relu), persistent form.
+extern "C" int fea_conv3x3p_bias_relu(const void* x, int ldx, const void* w_frag, const float* bias, void* y, int ldy,
+                                      void* pool, int ldpool, int N, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    C3pPlan p;
+    const char* who = "fea_conv3x3p_bias_relu";
+    int rc = c3p_check(who, x, ldx, w_frag, y, ldy, N, H, W, Cin, Cout, dtype, p);
+    if (rc) return rc;
+    FEA_CHECK(bias, FEA_E_BADARG, "%s: no bias", who);
+    FEA_CHECK(!pool || (ldpool >= Cout && ldpool % 8 == 0 && (uintptr_t)pool % 16 == 0), FEA_E_BADARG, "%s: pooled output layout", who);
+    C3pArgs a{};
+    c3p_fill(a, p, x, ldx, w_frag, y, ldy, H, W, Cout);
+    a.bias = bias; a.pool = (__bf16*)pool; a.ldpool = ldpool; a.pool_img_stride = (long long)(H / 2) * (W / 2) * ldpool;
+    dim3 grid((unsigned)(p.npixwg * p.nhalf)), block(256);
+    if (Cin == 64) hipLaunchKernelGGL((c3p_kernel<1, 3, 0>), grid, block, 0, (hipStream_t)stream, a);
+    else           hipLaunchKernelGGL((c3p_kernel<2, 3, 0>), grid, block, 0, (hipStream_t)stream, a);
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }

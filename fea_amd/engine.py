@@ -340,7 +340,7 @@ class UNetEngine:
         co, ci = p.shape[0], p.shape[1]
         return self._pack(name + "/f", p, p.numel(), "fea_pack_conv3x3", co, ci, 0)
 
-    def _w_folded(self, name: str):
+    def _w_folded(self, name: str, frag: bool = False):
         """Packed weights and bias of conv `name` with its eval-mode BatchNorm folded in:
         w' = w * gamma / sqrt(running_var + eps), b' = (b - running_mean) * that + beta
         (models.py:28-29 / 31-32 in eval mode).  Re-made when any of the six tensors changes."""
@@ -350,7 +350,7 @@ class UNetEngine:
         deps = [P[name + ".weight"], P[name + ".bias"], P[bn + ".weight"], P[bn + ".bias"],
                 B[bn + ".running_mean"], B[bn + ".running_var"]]
         ver = (self._gen, tuple(t._version for t in deps), tuple(t.data_ptr() for t in deps))
-        ent = self.folded.get(name)
+        ent = self.folded.get((name, frag))
         if ent is None or ent[0] != ver:
             with torch.no_grad():
                 scale = deps[2] * torch.rsqrt(deps[5] + BN_EPS)
@@ -361,11 +361,11 @@ class UNetEngine:
                 ks = (9 * self.in_channels + 31) // 32
                 numel, fn, args = ks * 64 * 32, "fea_pack_conv3x3_first", (64, self.in_channels)
             else:
-                numel, fn, args = wf.numel(), "fea_pack_conv3x3", (co, ci, 0)
+                numel, fn, args = wf.numel(), ("fea_pack_conv3x3_frag" if frag else "fea_pack_conv3x3"), (co, ci, 0)
             buf = ent[1] if ent is not None else torch.empty(numel, dtype=self.dtype, device=self.device)
             L.call(fn, wf, buf, *args, self.code, L.stream_ptr())
             ent = (ver, buf, bf)
-            self.folded[name] = ent
+            self.folded[(name, frag)] = ent
         return ent[1], ent[2]
 
     def _w_dgrad(self, name: str, frag: bool = False):
@@ -463,12 +463,13 @@ class UNetEngine:
             """conv -> BN statistics -> scale/shift -> ReLU(+pool)"""
             if fold and (name != "enc1.0" or self.first_direct):
                 # eval mode: one kernel, relu(conv(x, w') + b') (+ pooled copy)
-                wp, bf = self._w_folded(name)
+                rows_p = self._p_modes(pl)[name][0]
+                wp, bf = self._w_folded(name, frag=rows_p > 0)
                 if name == "enc1.0":
                     L.call("fea_conv3x3_first_bias_relu", pl.x_in, wp, bf, out_full, ld_full, N, self.in_channels, h, w, cout, code, S)
                 else:
-                    L.call("fea_conv3x3_bias_relu", inp, ld_in, wp, bf, out_full, ld_full, out_pool, cout if out_pool is not None else 0,
-                           N, h, w, cin, cout, code, S)
+                    L.call("fea_conv3x3p_bias_relu" if rows_p else "fea_conv3x3_bias_relu", inp, ld_in, wp, bf, out_full, ld_full,
+                           out_pool, cout if out_pool is not None else 0, N, h, w, cin, cout, code, S)
                 return
             y = pl.y[name]
             stats = pl.stats if training else None

@@ -114,7 +114,9 @@ int fea_conv3x3_dgrad_bnred(const void* dy, int lddy, const void* w_packed, void
  * pixel tiles with the weight fragments resident in registers.  w_frag: fea_pack_conv3x3_frag (same arguments as
  * fea_pack_conv3x3, always MFMA fragment order).  The partial-sum tables they write have fea_conv3x3p_rows() rows
  * (2 per workgroup, not one per pixel tile); fea_conv3x3p_rows() == 0 means the shape is not served: use the
- * plain entry points.  Same results as the plain entry points up to fp32 summation order. */
+ * plain entry points.  Same results as the plain entry points up to fp32 summation order.  With bias == NULL
+ * (a data gradient) fea_conv3x3p's `stats` carries only sum y (slot 1 is 0).  fea_conv3x3p_bias_relu is the
+ * persistent form of fea_conv3x3_bias_relu (declared below). */
 int fea_pack_conv3x3_frag(const float* w, void* out, int Co, int Ci, int dgrad, int dtype, void* stream);
 int fea_conv3x3p_rows(int N, int H, int W, int Cin, int Cout, int dtype);
 int fea_conv3x3p(const void* x, int ldx, const void* w_frag, const float* bias, void* y, int ldy,
@@ -123,6 +125,8 @@ int fea_conv3x3p_dgrad_bnred(const void* dy, int lddy, const void* w_frag, void*
                              const void* y, int ldy_bn, const float* scale, const float* shift,
                              const float* save_mean, const float* save_invstd, float* part,
                              int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+int fea_conv3x3p_bias_relu(const void* x, int ldx, const void* w_frag, const float* bias, void* y, int ldy,
+                           void* pool, int ldpool, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
 /* Eval-mode inference with BatchNorm folded into the packed weights and the bias
  * (w' = w * gamma/sqrt(var+eps) per output channel, b' = (b - mean) * that + beta):
  * Conv2d -> BatchNorm2d(eval) -> ReLU of models.py:28-33 in one kernel,

@@ -207,6 +207,35 @@ def test_persistent_conv3x3_fwd_stats_dgrad_and_bnred(shape):
     assert rel_l2(got[:, 0], want[:, 0]) < 1e-5 and rel_l2(got[:, 1], want[:, 1]) < 1e-4, (rel_l2(got[:, 0], want[:, 0]), rel_l2(got[:, 1], want[:, 1]))
 
 
+@pytest.mark.parametrize("shape", SHAPES_P)
+@pytest.mark.parametrize("pooled", [False, True])
+def test_persistent_conv3x3_bias_relu_pool_inference(shape, pooled):
+    """fea_conv3x3p_bias_relu (folded-BatchNorm inference, persistent form) against F.conv2d / relu / max_pool2d on
+    bf16-rounded inputs; the pooled output must be exactly the max over the stored (bf16) activations."""
+    dt = torch.bfloat16
+    code = L.dt_code(dt)
+    n, h, w, ci, co = shape
+    g = torch.Generator().manual_seed(33)
+    x = rnd(dt, n, ci, h, w, gen=g)
+    wt = (rnd(dt, co, ci, 3, 3, gen=g) / (3 * ci ** 0.5)).to(dt).float()
+    bias = torch.randn(co, generator=g) * 0.3
+    ref = F.relu(F.conv2d(x, wt, bias, padding=1))
+    wp = torch.empty(9 * co * ci, dtype=dt, device=DEV)
+    L.call("fea_pack_conv3x3_frag", wt.to(DEV), wp, co, ci, 0, code, S())
+    ldy, off = co + 64, 64
+    y = torch.full((n, h, w, ldy), float("nan"), dtype=dt, device=DEV)
+    pool = torch.full((n, h // 2, w // 2, co + 8), float("nan"), dtype=dt, device=DEV) if pooled else None
+    L.call("fea_conv3x3p_bias_relu", to_nhwc(x, dt), ci, wp, bias.to(DEV), view_ptr(y, off), ldy,
+           view_ptr(pool, 8) if pooled else None, co + 8 if pooled else 0, n, h, w, ci, co, code, S())
+    torch.cuda.synchronize()
+    got = from_nhwc(y, co, off)
+    check(got, ref, dt, "persistent conv+bias+relu")
+    assert (got >= 0).all() and torch.isnan(y[..., :off].float()).all()
+    if pooled:
+        assert torch.equal(from_nhwc(pool, co, 8), F.max_pool2d(got, 2)), "pooled output != max of the stored activations"
+        assert torch.isnan(pool[..., :8].float()).all()
+
+
 def test_persistent_conv3x3_rejects_shapes_it_does_not_serve():
     code = L.dt_code(torch.bfloat16)
     assert L.call("fea_conv3x3p_rows", 1, 24, 40, 64, 64, code) == 0          # W % 32
