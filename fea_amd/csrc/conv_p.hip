@@ -52,7 +52,10 @@ constexpr int P_ROWS = 352;                   // >= (8+2)*(32+2) = 340, multiple
 constexpr int P_STAGE = P_ROWS * 128;         // bytes of one halo stage
 constexpr int P_NDMA = 11;                    // 1 KB LDS-DMA pieces per wave per stage (44 pieces)
 
-__device__ __forceinline__ int p_swz(int row) { return (row >> 1) & 7; }
+// XOR applied to a row's 16-byte chunk index.  A ds_read_b128 is served in groups of 16 lanes = 16 consecutive halo rows, 8 of
+// them reading chunk q and 8 chunk q ^ 1 (MI355X_MICROARCH.md, LDS table): bit 0 of the chunk is left alone so the two subsets
+// never meet, and 8 consecutive rows get 8 distinct (row parity, XOR) pairs -- conflict-free for every base row and tap.
+__device__ __forceinline__ int p_swz(int row) { return ((row >> 1) & 3) << 1; }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     const f32x2 v = {a, b};
@@ -63,8 +66,16 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 //        is written as 0: the ConvTranspose2d bias gradient taken from a data-gradient launch), STATS 0: none
 // EPI 2: da = conv (no bias) + fused first pass of the next BatchNorm backward (sum g, sum g*xhat)
 // EPI 3: inference with BatchNorm folded into weights and bias: relu(conv + bias), plus its MaxPool2d(2) when g.pool is set
+#ifndef P_PIN2
+#define P_PIN2 7
+#endif
 template <int NCH, int EPI, int STATS>
 __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
+    // OVL (K = 576): a tile is multiplied as two pixel halves (accumulator tiles m = 0..3, then 4..7, 18 k-steps each);
+    // the epilogue of one half is issued, a micro-operation or two at a time, between the MFMA pairs of the other half
+    // (of the same tile for the first half, of the next tile for the second), so it costs issue slots but no MFMA
+    // idle time and no extra registers.  With K = 1152 both LDS stages hold the current tile: no room to run ahead.
+    constexpr bool OVL = NCH == 1 && EPI != 3;
     constexpr int YB = EPI == 2 ? 4 * 8192 : 0;        // per-wave private y tiles (128 px x 64 B)
     __shared__ __attribute__((aligned(128))) char smem[2 * P_STAGE + YB + 256];
 
@@ -73,8 +84,9 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, q16 = lane >> 4;
     int pw, half;
-    if (g.nhalf == 2 && (g.npixwg & 7) == 0) { half = (blockIdx.x >> 3) & 1; pw = (blockIdx.x & 7) + 8 * (blockIdx.x >> 4); }
-    else { half = blockIdx.x / g.npixwg; pw = blockIdx.x - half * g.npixwg; }
+    if (g.nhalf > 1 && (g.npixwg & 7) == 0) {        // blocks b, b + 8, ... (one XCD) take the column groups of the same tiles
+        half = (blockIdx.x >> 3) % g.nhalf; pw = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * g.nhalf));
+    } else { half = blockIdx.x / g.npixwg; pw = blockIdx.x - half * g.npixwg; }
     const int W = g.W;
     const int cbase = half * 64 + wn * 32;              // first GEMM column of this wave
 
@@ -95,6 +107,21 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
                         Wf[c][tap][ks][n] = *reinterpret_cast<const u32x4*>(
                             wb + ((long long)((c * 9 + tap) * nt16 + (cbase >> 4) + n) * 2 + ks) * 512);
     }
+
+    // The weight fragments are only ever MFMA operands: keep them in the accumulation half of the register file, so that
+    // the 256 architectural registers hold the A ring, the addresses and the epilogue's temporaries without copies
+    auto pin_weights = [&]() {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    asm volatile("" : "+a"(Wf[0][tap][ks][n]));
+                    if constexpr (NCH == 2 && P_PIN2 > 0) if (tap < P_PIN2) asm volatile("" : "+a"(Wf[1][tap][ks][n]));
+                }
+    };
+    pin_weights();
 
     // ---- A (pixel) fragment addresses: halo rows wm*4 .. wm*4+5, dx 0..2, x = r16 (odd m: +2048 bytes) ----
     uint32_t abase[6][3];
@@ -202,8 +229,12 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
             constexpr int nstep = step + 1, ntap = nstep >> 1, nks = nstep & 1, ndy = ntap / 3, ndx = ntap % 3;
             sfor<0, 8>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                if constexpr (nstep < 18) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(A[m]));
-                else                      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(A[m]) : "n"(7 - m));
+                // one wait per two MFMA pairs (fragments m and m + 1: 6 reads in flight behind them); no register operand,
+                // so the compiler pads no hazard state behind the statement -- the sched_barrier keeps the MFMAs below it
+                if constexpr ((m & 1) == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(nstep < 18 ? 6 : 6 - m) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[C][tap][ks][n]),
@@ -237,6 +268,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     auto item = [&](int t, auto cc, auto sc_) {
         constexpr int C = decltype(cc)::value, STG = decltype(sc_)::value;
         STAMP(4);
+        pin_weights();
         // this wave's DMA pieces of this stage have landed (the vmcnt(0) behind the previous stage's MFMAs / the
         // prologue); after the barrier every wave's have, and every wave is done reading the other stage
         __builtin_amdgcn_s_barrier();
@@ -310,8 +342,11 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
                 if constexpr (EPI == 0 && STATS >= 1) {
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
-                        S[n] += acc[m][n];
-                        if constexpr (STATS == 2) Q[n] = __builtin_elementwise_fma(acc[m][n], acc[m][n], Q[n]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {          // scalar on purpose: packed f32 VALU is slower beside MFMAs
+                            S[n][e] += acc[m][n][e];
+                            if constexpr (STATS == 2) Q[n][e] = __builtin_fmaf(acc[m][n][e], acc[m][n][e], Q[n][e]);
+                        }
                     }
                 }
                 uint32_t lo0 = pack_bf16x2(acc[m][0][0], acc[m][0][1]), hi0 = pack_bf16x2(acc[m][0][2], acc[m][0][3]);
@@ -338,6 +373,154 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
         }
     };
 
+    // ---- overlapped form (OVL) ----------------------------------------------------------------------------------
+    // one pixel half (accumulator tiles 4 HALF .. 4 HALF + 3) over the 18 k-steps of a stage.  A fragments: ring of
+    // 8 = 2 k-steps x 4 tiles, re-read for k-step s + 2 right after the MFMA pair of k-step s: again 7 reads in flight
+    // behind the one a pair needs.  hook(slot) runs behind MFMA pair slot = 4 * step + mm (72 slots).
+    auto mma_half = [&](auto sc_, auto hc, auto&& hook) {
+        constexpr int STG = decltype(sc_)::value, HALF = decltype(hc)::value;
+        const uint32_t st = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        u32x4 A[8], bq[2];
+        lds_rd(bq[0], bias_addr, std::integral_constant<int, 0>{});
+        lds_rd(bq[1], bias_addr, std::integral_constant<int, 64>{});
+        sfor<0, 8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, step = i >> 2, m = HALF * 4 + (i & 3);
+            constexpr int tap = step >> 1, ks = step & 1, dy = tap / 3, dx = tap % 3;
+            lds_rd(A[i], st + (abase[(m >> 1) + dy][dx] ^ (uint32_t)(ks << 6)), std::integral_constant<int, STG * P_STAGE + (m & 1) * 2048>{});
+        });
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bq[0]), "+v"(bq[1]));
+        const f32x4 biasv[2] = {__builtin_bit_cast(f32x4, bq[0]), __builtin_bit_cast(f32x4, bq[1])};
+        sfor<0, 18>([&](auto stc) {
+            constexpr int step = decltype(stc)::value, tap = step >> 1, ks = step & 1;
+            constexpr int nstep = step + 2, ntap = nstep >> 1, nks = nstep & 1, ndy = ntap / 3, ndx = ntap % 3;
+            sfor<0, 4>([&](auto mc) {
+                constexpr int mm = decltype(mc)::value, m = HALF * 4 + mm, ai = (step & 1) * 4 + mm;
+                if constexpr ((mm & 1) == 0) {      // fragments mm and mm + 1 (see mma_stage)
+                    constexpr int inflight = step <= 15 ? 6 : (step == 16 ? 6 - mm : 2 - mm);
+                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(inflight) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[0][tap][ks][n]),
+                                                                        __builtin_bit_cast(bf16x8, A[ai]),
+                                                                        step == 0 ? biasv[n] : acc[m][n], 0, 0, 0);
+                if constexpr (nstep < 18)
+                    lds_rd(A[ai], st + (abase[(m >> 1) + ndy][ndx] ^ (uint32_t)(nks << 6)),
+                           std::integral_constant<int, STG * P_STAGE + (m & 1) * 2048>{});
+                hook(std::integral_constant<int, step * 4 + mm>{});
+            });
+        });
+    };
+    // micro-operations of the epilogue of accumulator tile m (k = 0 .. NPER - 1)
+    constexpr int NPER = EPI == 2 ? 16 : 8;
+    uint32_t pk[4]; u32x4 outv; bf16x8 yyv;            // live between the micro-operations of one m
+    auto epi_micro = [&](__bf16* yt, auto mcc, auto uc) {
+        constexpr int m = decltype(mcc)::value, u = decltype(uc)::value;
+        constexpr int UC = EPI == 2 ? 0 : 4;          // first of the four convert / exchange / store micro-operations
+        if constexpr (EPI == 0 && u < 4) {
+            constexpr int n = u >> 1;
+            // scalar on purpose: packed f32 VALU is slower beside MFMAs (the file is built without the SLP vectoriser)
+            if constexpr ((u & 1) == 0 && STATS >= 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[n][e] += acc[m][n][e];
+            }
+            if constexpr ((u & 1) == 1 && STATS == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Q[n][e] = __builtin_fmaf(acc[m][n][e], acc[m][n][e], Q[n][e]);
+            }
+        }
+        if constexpr (u == UC)     { pk[0] = pack_bf16x2(acc[m][0][0], acc[m][0][1]); pk[1] = pack_bf16x2(acc[m][0][2], acc[m][0][3]); }
+        if constexpr (u == UC + 1) { pk[2] = pack_bf16x2(acc[m][1][0], acc[m][1][1]); pk[3] = pack_bf16x2(acc[m][1][2], acc[m][1][3]); }
+        if constexpr (u == UC + 2) {
+            const auto r0 = __builtin_amdgcn_permlane16_swap(pk[0], pk[2], false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(pk[1], pk[3], false, false);
+            outv = u32x4{r0[0], r1[0], r0[1], r1[1]};
+        }
+        if constexpr (u == UC + 3) *reinterpret_cast<u32x4*>(yt + ((long long)(m >> 1) * W + (m & 1) * 16) * g.ldy) = outv;
+        if constexpr (EPI == 2) {
+            if constexpr (u == 4) yyv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ylds + m * 1024 + r16 * 64 + (chl >> 3) * 16));
+            if constexpr (u >= 5 && u < 13) {
+                constexpr int j = u - 5;
+                const bf16x8 dd = __builtin_bit_cast(bf16x8, outv);
+                const float yf = (float)yyv[j];
+                const float gg = __builtin_fmaf(yf, csc[j], csh[j]) > 0.f ? (float)dd[j] : 0.f;
+                a0[j] += gg; a1[j] = __builtin_fmaf(gg, yf, a1[j]);
+            }
+        }
+    };
+    // the 4 * NPER micro-operations of one half, spread over slots S0 .. 71 of the other half's MFMA pairs
+    auto epi_slot = [&](__bf16* yt, auto hc, auto s0c, auto slotc) {
+        constexpr int HALF = decltype(hc)::value, S0 = decltype(s0c)::value, slot = decltype(slotc)::value, NM = 4 * NPER;
+        constexpr int lo = slot <= S0 ? -1 : ((slot - S0) * NM) / (72 - S0) - 1;
+        constexpr int hi = slot < S0 ? -1 : ((slot - S0 + 1) * NM) / (72 - S0) - 1;
+        sfor<0, hi - lo>([&](auto dc) {
+            constexpr int k = lo + 1 + decltype(dc)::value;
+            epi_micro(yt, std::integral_constant<int, HALF * 4 + k / NPER>{}, std::integral_constant<int, k % NPER>{});
+        });
+    };
+    auto y_pieces = [&](auto hc) {      // EPI 2: this tile's pre-BN activations of one pixel half, the rows this wave reads itself
+        constexpr int HALF = decltype(hc)::value;
+        const __bf16* yb = g.ybn + (long long)ni * g.ybn_img_stride + ((long long)(ty * P_TH) * W + tx * P_TW) * g.ldybn + ybn_lane;
+#pragma unroll
+        for (int m = HALF * 4; m < HALF * 4 + 4; ++m) {
+            const __bf16* src = yb + ((long long)(m >> 1) * W + (m & 1) * 16 + (lane >> 2)) * g.ldybn + (lane & 3) * 8;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ylds + m * 1024), 16, 0, 0);
+        }
+    };
+    __bf16* prev_yt = nullptr;
+    auto item_ovl = [&](int t, auto sc_, auto fc) {
+        constexpr int STG = decltype(sc_)::value;
+        constexpr bool FIRST = decltype(fc)::value;       // no previous tile: no second-half epilogue to interleave
+        pin_weights();
+        __builtin_amdgcn_s_barrier();
+        int n2 = ni, x2 = tx, y2 = ty;
+        advance(n2, x2, y2);
+        const bool more = t + 1 < t1;
+        const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(more ? n2 : ni);
+        const int ntoff = tile_off(x2, y2, 0);
+        const unsigned nedge = more ? tile_edge(x2, y2) : 31u;
+        __bf16* const yt = g.y + (long long)ni * g.y_img_stride + ((long long)(ty * P_TH) * W + tx * P_TW) * g.ldy + y_lane;
+        if constexpr (EPI == 2) y_pieces(std::integral_constant<int, 0>{});
+        // first half: the next tile's 11 DMA pieces behind slots 1, 3, .. 21; from slot 24 on the previous tile's second-half epilogue
+        mma_half(sc_, std::integral_constant<int, 0>{}, [&](auto slotc) {
+            constexpr int slot = decltype(slotc)::value;
+            if constexpr ((slot & 1) == 1 && (slot >> 1) < P_NDMA) issue_piece(nrs, ntoff, nedge, STG ^ 1, std::integral_constant<int, (slot >> 1)>{});
+            if constexpr (!FIRST) epi_slot(prev_yt, std::integral_constant<int, 1>{}, std::integral_constant<int, 24>{}, slotc);
+        });
+        if constexpr (EPI == 2) {
+            // VM operations of this tile so far, in issue order: 4 y pieces, 11 DMA pieces, then (not FIRST) 4 stores
+            if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else                 asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            y_pieces(std::integral_constant<int, 1>{});          // second-half rows: last read by the epilogue just issued
+        }
+        // second half: this tile's first-half epilogue from slot 8 on
+        mma_half(sc_, std::integral_constant<int, 1>{}, [&](auto slotc) {
+            epi_slot(yt, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, slotc);
+        });
+        // everything but the first-half epilogue's 4 stores: the next stage (and the second-half y rows) have landed
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        prev_yt = yt;
+        advance(ni, tx, ty);
+    };
+
+    if constexpr (OVL) {
+        if (t0 < t1) {
+            item_ovl(t0, std::integral_constant<int, 0>{}, std::true_type{});
+            int t = t0 + 1;
+            while (t < t1) {
+                item_ovl(t, std::integral_constant<int, 1>{}, std::false_type{});
+                if (++t >= t1) break;
+                item_ovl(t, std::integral_constant<int, 0>{}, std::false_type{});
+                ++t;
+            }
+            // the last tile's second-half epilogue
+            sfor<0, 4 * NPER>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                epi_micro(prev_yt, std::integral_constant<int, 4 + k / NPER>{}, std::integral_constant<int, k % NPER>{});
+            });
+        }
+    } else
     if constexpr (NCH == 1) {
         for (int t = t0; t < t1; t += 2) {
             item(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -391,7 +574,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
 struct C3pPlan { int tiles_x, tiles_y, ntiles, nhalf, npixwg, tiles_per_wg; };
 
 static bool c3p_plan(int N, int H, int W, int Cin, int Cout, int dtype, C3pPlan& p) {
-    if (dtype != FEA_BF16 || (Cin != 64 && Cin != 128) || (Cout != 64 && Cout != 128)) return false;
+    if (dtype != FEA_BF16 || (Cin != 64 && Cin != 128) || (Cout != 64 && Cout != 128 && Cout != 256)) return false;
     if (H % P_TH || W % P_TW || N <= 0) return false;
     p.tiles_x = W / P_TW; p.tiles_y = H / P_TH;
     const long long nt = (long long)N * p.tiles_x * p.tiles_y;
@@ -416,7 +599,7 @@ static int c3p_check(const char* who, const void* x, int ldx, const void* w, con
                      int Cin, int Cout, int dtype, C3pPlan& p) {
     FEA_CHECK(x && w && y, FEA_E_BADARG, "%s: null pointer", who);
     FEA_CHECK(c3p_plan(N, H, W, Cin, Cout, dtype, p), FEA_E_UNSUPPORTED_SHAPE,
-              "%s: serves bf16, Cin and Cout in {64,128}, H %% 8 == 0, W %% 32 == 0 (got N=%d H=%d W=%d Cin=%d Cout=%d): use fea_conv3x3",
+              "%s: serves bf16, Cin in {64,128}, Cout in {64,128,256}, H %% 8 == 0, W %% 32 == 0 (got N=%d H=%d W=%d Cin=%d Cout=%d): use fea_conv3x3",
               who, N, H, W, Cin, Cout);
     FEA_CHECK(ldx >= Cin && ldy >= Cout && ldx % 8 == 0 && ldy % 8 == 0, FEA_E_BADARG, "%s: ldx=%d ldy=%d", who, ldx, ldy);
     FEA_CHECK(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)w % 16 == 0), FEA_E_BADARG, "%s: pointers must be 16-byte aligned", who);
