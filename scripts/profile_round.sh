@@ -13,4 +13,6 @@ BENCH1="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timi
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT -o ${TAG}_fetch --output-format csv -- $BENCH1 > $OUT/${TAG}_fetch.log 2>&1
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d $OUT -o ${TAG}_write --output-format csv -- $BENCH1 > $OUT/${TAG}_write.log 2>&1
 timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT -o ${TAG}_mfma --output-format csv -- $BENCH1 > $OUT/${TAG}_mfma.log 2>&1
+# issue / wait / LDS breakdown per kernel (SQ block, 8 counters)
+timeout -s KILL 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU -d $OUT -o ${TAG}_sq --output-format csv -- $BENCH1 > $OUT/${TAG}_sq.log 2>&1
 ls -la $OUT | head -30
