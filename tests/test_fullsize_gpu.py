@@ -33,6 +33,7 @@ def setup():
 
 def _fwd_bwd(m, x, t, scale=1.0, overlap=True):
     eng = m._engine()
+    default = eng.overlap_wgrad
     eng.overlap_wgrad = overlap
     state = {k: v.clone() for k, v in m.state_dict().items()}     # forward updates the BN buffers
     logits = eng.forward(x, True).clone()
@@ -41,7 +42,7 @@ def _fwd_bwd(m, x, t, scale=1.0, overlap=True):
     torch.cuda.synchronize()
     grads = eng.flat_grad.clone()
     m.load_state_dict(state)
-    eng.overlap_wgrad = True
+    eng.overlap_wgrad = default
     return logits, loss.clone(), grads
 
 
