@@ -42,14 +42,16 @@ def main():
                 "ms": ms, "images_per_s": 64e3 / ms, "tflops": 64 * GF512 / ms}
         eng.fold_bn = True
         del x
-        big = torch.randn(2, 3, 2048, 2048, device="cuda")
-        tgt = (torch.rand(2, 6, 2048, 2048, device="cuda") < 0.1).to(torch.uint8)
+        NB = 4
+        big = torch.randn(NB, 3, 2048, 2048, device="cuda")
+        tgt = (torch.rand(NB, 6, 2048, 2048, device="cuda") < 0.1).to(torch.uint8)
         from fea_amd.inference import window_plan
-        for core, wb in ((512, 16), (1024, 4), ((1024, 2048), 2)):
-            seg = TiledSegmenter(m, core=core, window_batch=wb)
+        for core in (512, 1024, (1024, 2048)):
+            seg = TiledSegmenter(m, core=core)          # windows per forward: the default pixel budget
             ms = timed(lambda: seg.segment(big, tgt), 3)
             wh, ww, plan = window_plan(2048, 2048, core)
-            out[f"tiled2048_core{core}"] = {"ms_per_image": ms / 2, "images_per_s": 2e3 / ms, "useful_tflops": 2 * 16 * GF512 / ms,
+            out[f"tiled2048_core{core}"] = {"ms_per_image": ms / NB, "images_per_s": NB * 1e3 / ms, "useful_tflops": NB * 16 * GF512 / ms,
+                                            "images_per_call": NB, "windows_per_forward": max(1, seg.PIXELS_PER_FORWARD // (wh * ww)),
                                             "windows_per_image": len(plan), "window": [wh, ww],
                                             "computed_over_useful_pixels": len(plan) * wh * ww / 2048.0 ** 2}
     print(json.dumps({"metric": "UNet inference throughput bf16", "data": "synthetic", **out}))
