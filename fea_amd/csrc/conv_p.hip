@@ -66,9 +66,25 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 //        is written as 0: the ConvTranspose2d bias gradient taken from a data-gradient launch), STATS 0: none
 // EPI 2: da = conv (no bias) + fused first pass of the next BatchNorm backward (sum g, sum g*xhat)
 // EPI 3: inference with BatchNorm folded into weights and bias: relu(conv + bias), plus its MaxPool2d(2) when g.pool is set
+// cache-policy switches (A/B): aux operand of the halo LDS-DMA and of the y-row LDS-DMA (2 = nt), nontemporal output stores.
+// All three measured SLOWER in the training step (persistent kernels 10.95 -> 11.35 / 10.99 / 11.34 ms, fused-reduction
+// launches 2.81 -> 2.77 / 3.11 / 3.03): halos and freshly written rows are re-read through L2.  Defaults stay 0.
+#ifndef P_AUX_X
+#define P_AUX_X 0
+#endif
+#ifndef P_AUX_Y
+#define P_AUX_Y 0
+#endif
+#ifndef P_NT_ST
+#define P_NT_ST 0
+#endif
 #ifndef P_PIN2
 #define P_PIN2 7
 #endif
+__device__ __forceinline__ void st_out(__bf16* p, const u32x4& v) {
+    if constexpr (P_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+    else *reinterpret_cast<u32x4*>(p) = v;
+}
 template <int NCH, int EPI, int STATS>
 __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     // OVL (K = 576): a tile is multiplied as two pixel halves (accumulator tiles m = 0..3, then 4..7, 18 k-steps each);
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
         constexpr int i = decltype(ic)::value;
         const unsigned f = ((i < 6 ? fl0 >> (5 * i) : fl1 >> (5 * (i - 6))) & edge) & 31u;
         const int voff = f ? (int)0xfffffff0u : toff + rel[i];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + stage * P_STAGE + (4 * i + wave) * 1024), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + stage * P_STAGE + (4 * i + wave) * 1024), 16, voff, 0, 0, P_AUX_X);
     };
     auto issue = [&](int n_img, int tx, int ty, int c, int stage) {
         const __amdgpu_buffer_rsrc_t rs = tile_rsrc(n_img);
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const __bf16* src = yb + ((long long)(m >> 1) * W + (m & 1) * 16 + (lane >> 2)) * g.ldybn + (lane & 3) * 8;
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ylds + m * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ylds + m * 1024), 16, 0, P_AUX_Y);
             }
         }
         mma_stage(cc, sc_, [&](auto stc, auto mc) {
@@ -355,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
                 const auto r0 = __builtin_amdgcn_permlane16_swap(lo0, lo1, false, false);
                 const auto r1 = __builtin_amdgcn_permlane16_swap(hi0, hi1, false, false);
                 const u32x4 out = {r0[0], r1[0], r0[1], r1[1]};
-                *reinterpret_cast<u32x4*>(yt + ((long long)(m >> 1) * W + (m & 1) * 16) * g.ldy) = out;
+                st_out(yt + ((long long)(m >> 1) * W + (m & 1) * 16) * g.ldy, out);
                 if constexpr (EPI == 2) {
                     // lane (pixel r16 of tile m, channels chl..chl+7): y row at ylds + m*1024 + r16*64 + piece*16
                     const u32x4 yv = *reinterpret_cast<const u32x4*>(ylds + m * 1024 + r16 * 64 + (chl >> 3) * 16);
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
             const auto r1 = __builtin_amdgcn_permlane16_swap(pk[1], pk[3], false, false);
             outv = u32x4{r0[0], r1[0], r0[1], r1[1]};
         }
-        if constexpr (u == UC + 3) *reinterpret_cast<u32x4*>(yt + ((long long)(m >> 1) * W + (m & 1) * 16) * g.ldy) = outv;
+        if constexpr (u == UC + 3) st_out(yt + ((long long)(m >> 1) * W + (m & 1) * 16) * g.ldy, outv);
         if constexpr (EPI == 2) {
             if constexpr (u == 4) yyv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ylds + m * 1024 + r16 * 64 + (chl >> 3) * 16));
             if constexpr (u >= 5 && u < 13) {
@@ -465,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
 #pragma unroll
         for (int m = HALF * 4; m < HALF * 4 + 4; ++m) {
             const __bf16* src = yb + ((long long)(m >> 1) * W + (m & 1) * 16 + (lane >> 2)) * g.ldybn + (lane & 3) * 8;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ylds + m * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ylds + m * 1024), 16, 0, P_AUX_Y);
         }
     };
     __bf16* prev_yt = nullptr;

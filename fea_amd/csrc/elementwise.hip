@@ -263,6 +263,21 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     shift[c] = beta[c] - rm[c] * sc;
 }
 
+// Streaming access hints of the BatchNorm passes (A/B switches; bit 0: nontemporal loads in the backward passes, bit 1:
+// nontemporal stores, bit 2: nontemporal loads of y in the forward pass).  Measured on one box, ms per step: backward
+// apply 9.63 -> 9.27 and reduce 2.31 -> 2.06 with bit 0, forward 5.75 -> 5.62 with bit 2, stores: no change.
+#ifndef BN_NT
+#define BN_NT 5
+#endif
+__device__ __forceinline__ u32x4 bn_ld(const void* p) {
+    if constexpr (BN_NT & 1) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    else return *reinterpret_cast<const u32x4*>(p);
+}
+__device__ __forceinline__ void bn_st(void* p, const u32x4& v) {
+    if constexpr (BN_NT & 2) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+    else *reinterpret_cast<u32x4*>(p) = v;
+}
+
 // ---------------------------------------------------------------------------
 // BN + ReLU (+ 2x2 max-pool) forward
 // ---------------------------------------------------------------------------
@@ -287,10 +302,11 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const T* __restrict__
     if (!POOL) {
         const long long p = ((long long)n * H + yo) * W + xo;
         float f[V];
-        unpack<T>(*reinterpret_cast<const u32x4*>(y + p * C + grp * V), f);
+        unpack<T>((BN_NT & 4) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(y + p * C + grp * V))
+                              : *reinterpret_cast<const u32x4*>(y + p * C + grp * V), f);
 #pragma unroll
         for (int j = 0; j < V; ++j) f[j] = bn_act(f[j], sc[j], sh[j]);
-        *reinterpret_cast<u32x4*>(out_full + p * ld_full + grp * V) = pack<T>(f);
+        bn_st(out_full + p * ld_full + grp * V, pack<T>(f));
     } else {
         float mx[V];
 #pragma unroll
@@ -299,7 +315,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const T* __restrict__
         for (int w4 = 0; w4 < 4; ++w4) {
             const long long p = ((long long)n * H + 2 * yo + (w4 >> 1)) * W + 2 * xo + (w4 & 1);
             float f[V];
-            unpack<T>(*reinterpret_cast<const u32x4*>(y + p * C + grp * V), f);
+            unpack<T>((BN_NT & 4) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(y + p * C + grp * V))
+                                  : *reinterpret_cast<const u32x4*>(y + p * C + grp * V), f);
 #pragma unroll
             for (int j = 0; j < V; ++j) { f[j] = bn_act(f[j], sc[j], sh[j]); mx[j] = fmaxf(mx[j], f[j]); }
             *reinterpret_cast<u32x4*>(out_full + p * ld_full + grp * V) = pack<T>(f);
@@ -364,8 +381,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const T* __restrict__ 
             for (int w4 = 0; w4 < NP; ++w4) {
                 pidx[u][w4] = POOL ? ((long long)n * H + 2 * yo + (w4 >> 1)) * W + 2 * xo + (w4 & 1)
                                    : ((long long)n * H + yo) * W + xo;
-                ry[u][w4] = *reinterpret_cast<const u32x4*>(y + pidx[u][w4] * C + grp * V);
-                if (da_full) rg[u][w4] = *reinterpret_cast<const u32x4*>(da_full + pidx[u][w4] * ld_da + grp * V);
+                ry[u][w4] = bn_ld(y + pidx[u][w4] * C + grp * V);
+                if (da_full) rg[u][w4] = bn_ld(da_full + pidx[u][w4] * ld_da + grp * V);
             }
             if (POOL && dpool) rp[u] = *reinterpret_cast<const u32x4*>(dpool + (((long long)n * Ho + yo) * Wo + xo) * C + grp * V);
         }
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const T* __restrict__ 
                         o[j] = d; a0[j] += d;
                     }
                 }
-                if (APPLY) *reinterpret_cast<u32x4*>(dy + pidx[u][w4] * C + grp * V) = pack<T>(o);
+                if (APPLY) bn_st(dy + pidx[u][w4] * C + grp * V, pack<T>(o));
             }
         }
     }
