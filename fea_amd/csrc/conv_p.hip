@@ -391,39 +391,50 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
 
     // ---- overlapped form (OVL) ----------------------------------------------------------------------------------
     // one pixel half (accumulator tiles 4 HALF .. 4 HALF + 3) over the 18 k-steps of a stage.  A fragments: ring of
-    // 8 = 2 k-steps x 4 tiles, re-read for k-step s + 2 right after the MFMA pair of k-step s: again 7 reads in flight
-    // behind the one a pair needs.  hook(slot) runs behind MFMA pair slot = 4 * step + mm (72 slots).
-    auto mma_half = [&](auto sc_, auto hc, auto&& hook) {
-        constexpr int STG = decltype(sc_)::value, HALF = decltype(hc)::value;
+    // 8 = 2 k-steps x 4 tiles, re-read for k-step s + 2 right after the MFMA pair of k-step s: 7 reads in flight
+    // behind the one a pair needs.  The ring never drains: k-steps 16 and 17 refill it with k-steps 0 and 1 of the NEXT half
+    // (second half of this tile, or first half of the next tile in the other stage), behind that half's two bias reads,
+    // so a half starts with its operands already on their way.  hook(slot) runs behind MFMA pair slot = 4 * step + mm
+    // (72 slots); before16() runs in front of k-step 16 (the second half puts the tile's barrier there).
+    u32x4 Ar[8], bqr[2];
+    auto prime_reads = [&](auto sc_, auto hc, auto stepc, auto mmc) {     // read of (stage, half, k-step 0 / 1, tile mm) into its ring slot
+        constexpr int STG = decltype(sc_)::value, HALF = decltype(hc)::value, step = decltype(stepc)::value, mm = decltype(mmc)::value;
+        constexpr int m = HALF * 4 + mm, ks = step & 1;
         const uint32_t st = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-        u32x4 A[8], bq[2];
-        lds_rd(bq[0], bias_addr, std::integral_constant<int, 0>{});
-        lds_rd(bq[1], bias_addr, std::integral_constant<int, 64>{});
-        sfor<0, 8>([&](auto ic) {
-            constexpr int i = decltype(ic)::value, step = i >> 2, m = HALF * 4 + (i & 3);
-            constexpr int tap = step >> 1, ks = step & 1, dy = tap / 3, dx = tap % 3;
-            lds_rd(A[i], st + (abase[(m >> 1) + dy][dx] ^ (uint32_t)(ks << 6)), std::integral_constant<int, STG * P_STAGE + (m & 1) * 2048>{});
-        });
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bq[0]), "+v"(bq[1]));
-        const f32x4 biasv[2] = {__builtin_bit_cast(f32x4, bq[0]), __builtin_bit_cast(f32x4, bq[1])};
+        lds_rd(Ar[step * 4 + mm], st + (abase[m >> 1][0] ^ (uint32_t)(ks << 6)), std::integral_constant<int, STG * P_STAGE + (m & 1) * 2048>{});
+    };
+    auto prime_bias = [&]() {
+        lds_rd(bqr[0], bias_addr, std::integral_constant<int, 0>{});
+        lds_rd(bqr[1], bias_addr, std::integral_constant<int, 64>{});
+    };
+    auto mma_half = [&](auto sc_, auto hc, auto&& hook, auto&& before16) {
+        constexpr int STG = decltype(sc_)::value, HALF = decltype(hc)::value;
+        constexpr int NSTG = HALF ? STG ^ 1 : STG, NHALF = HALF ^ 1;          // the half whose first two k-steps this one reads ahead
+        const uint32_t st = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        // on entry: 2 bias reads, then the 8 reads of k-steps 0 and 1 are in flight (prime_* of the previous half or of the first tile)
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bqr[0]), "+v"(bqr[1]));
+        const f32x4 biasv[2] = {__builtin_bit_cast(f32x4, bqr[0]), __builtin_bit_cast(f32x4, bqr[1])};
         sfor<0, 18>([&](auto stc) {
             constexpr int step = decltype(stc)::value, tap = step >> 1, ks = step & 1;
             constexpr int nstep = step + 2, ntap = nstep >> 1, nks = nstep & 1, ndy = ntap / 3, ndx = ntap % 3;
+            if constexpr (step == 16) { before16(); prime_bias(); }
             sfor<0, 4>([&](auto mc) {
                 constexpr int mm = decltype(mc)::value, m = HALF * 4 + mm, ai = (step & 1) * 4 + mm;
-                if constexpr ((mm & 1) == 0) {      // fragments mm and mm + 1 (see mma_stage)
-                    constexpr int inflight = step <= 15 ? 6 : (step == 16 ? 6 - mm : 2 - mm);
-                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(inflight) : "memory");
+                if constexpr ((mm & 1) == 0) {      // fragments mm and mm + 1: 6 ring reads in flight behind them (never fewer: no tail)
+                    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[0][tap][ks][n]),
-                                                                        __builtin_bit_cast(bf16x8, A[ai]),
+                                                                        __builtin_bit_cast(bf16x8, Ar[ai]),
                                                                         step == 0 ? biasv[n] : acc[m][n], 0, 0, 0);
                 if constexpr (nstep < 18)
-                    lds_rd(A[ai], st + (abase[(m >> 1) + ndy][ndx] ^ (uint32_t)(nks << 6)),
+                    lds_rd(Ar[ai], st + (abase[(m >> 1) + ndy][ndx] ^ (uint32_t)(nks << 6)),
                            std::integral_constant<int, STG * P_STAGE + (m & 1) * 2048>{});
+                else
+                    prime_reads(std::integral_constant<int, NSTG>{}, std::integral_constant<int, NHALF>{},
+                                std::integral_constant<int, nstep - 18>{}, mc);
                 hook(std::integral_constant<int, step * 4 + mm>{});
             });
         });
@@ -484,18 +495,38 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
             __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ylds + m * 1024), 16, 0, P_AUX_Y);
         }
     };
+    // stores among the first-half epilogue's micro-operations that are issued before slot `lim` of the second half
+    constexpr int S0B = 8, NMB = 4 * NPER;
+    auto stores_before = [](int lim) constexpr {
+        int n = 0;
+        for (int slot = S0B; slot < lim; ++slot) {
+            const int lo = slot <= S0B ? -1 : ((slot - S0B) * NMB) / (72 - S0B) - 1, hi = ((slot - S0B + 1) * NMB) / (72 - S0B) - 1;
+            for (int k = lo + 1; k <= hi; ++k) n += (k % NPER) == (EPI == 2 ? 3 : 7) ? 1 : 0;
+        }
+        return n;
+    };
+    constexpr int NSTB = stores_before(64);          // k-step 16 = slot 64
     __bf16* prev_yt = nullptr;
     auto item_ovl = [&](int t, auto sc_, auto fc) {
         constexpr int STG = decltype(sc_)::value;
         constexpr bool FIRST = decltype(fc)::value;       // no previous tile: no second-half epilogue to interleave
         pin_weights();
-        __builtin_amdgcn_s_barrier();
+        if constexpr (FIRST) {
+            // the first tile's pieces were waited for in the prologue; every later tile's barrier sits at k-step 16 of the
+            // tile before it (below), and its ring is primed from there
+            __builtin_amdgcn_s_barrier();
+            prime_bias();
+            sfor<0, 8>([&](auto ic) {
+                prime_reads(sc_, std::integral_constant<int, 0>{}, std::integral_constant<int, (decltype(ic)::value >> 2)>{},
+                            std::integral_constant<int, (decltype(ic)::value & 3)>{});
+            });
+        }
         int n2 = ni, x2 = tx, y2 = ty;
         advance(n2, x2, y2);
         const bool more = t + 1 < t1;
         const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(more ? n2 : ni);
         const int ntoff = tile_off(x2, y2, 0);
-        const unsigned nedge = more ? tile_edge(x2, y2) : 31u;
+        const unsigned nedge = more ? tile_edge(x2, y2) : 31u;          // nothing follows: zeros (the ring still reads that stage ahead)
         __bf16* const yt = g.y + (long long)ni * g.y_img_stride + ((long long)(ty * P_TH) * W + tx * P_TW) * g.ldy + y_lane;
         if constexpr (EPI == 2) y_pieces(std::integral_constant<int, 0>{});
         // first half: the next tile's 11 DMA pieces behind slots 1, 3, .. 21; from slot 24 on the previous tile's second-half epilogue
@@ -503,19 +534,23 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
             constexpr int slot = decltype(slotc)::value;
             if constexpr ((slot & 1) == 1 && (slot >> 1) < P_NDMA) issue_piece(nrs, ntoff, nedge, STG ^ 1, std::integral_constant<int, (slot >> 1)>{});
             if constexpr (!FIRST) epi_slot(prev_yt, std::integral_constant<int, 1>{}, std::integral_constant<int, 24>{}, slotc);
-        });
+        }, [] {});
         if constexpr (EPI == 2) {
             // VM operations of this tile so far, in issue order: 4 y pieces, 11 DMA pieces, then (not FIRST) 4 stores
             if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
             else                 asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
             y_pieces(std::integral_constant<int, 1>{});          // second-half rows: last read by the epilogue just issued
         }
-        // second half: this tile's first-half epilogue from slot 8 on
+        // second half: this tile's first-half epilogue from slot 8 on.  In front of k-step 16 the tile's barrier: every
+        // VM operation but the NSTB stores issued since (so the next stage's pieces and the second-half y rows) has landed,
+        // and every LDS read of this stage has completed (the last were issued two k-steps ago) -- after the barrier the
+        // other stage may be read (ring refill of k-steps 16 / 17) and this one overwritten (the next tile's DMA pieces).
         mma_half(sc_, std::integral_constant<int, 1>{}, [&](auto slotc) {
-            epi_slot(yt, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, slotc);
+            epi_slot(yt, std::integral_constant<int, 0>{}, std::integral_constant<int, S0B>{}, slotc);
+        }, [&] {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NSTB) : "memory");
+            __builtin_amdgcn_s_barrier();
         });
-        // everything but the first-half epilogue's 4 stores: the next stage (and the second-half y rows) have landed
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         prev_yt = yt;
         advance(ni, tx, ty);
     };
