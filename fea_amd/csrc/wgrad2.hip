@@ -19,6 +19,7 @@
 //     cross-workgroup reduction is a plain vector sum.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
@@ -33,6 +34,7 @@ struct Wgrad2Args {
     int M, Nn;
     int tiles_x, tiles_y, ntiles, tiles_per_split;
     int nmt, nnt;
+    unsigned long long* dbg;      // WG2_STAMPS builds only: per-wave phase cycle sums [workgroup][wave][6]
 };
 
 __device__ __forceinline__ int swzw2(int x) {      // bit-reverse of bits 1..3 of x (as wgrad.hip)
@@ -40,29 +42,31 @@ __device__ __forceinline__ int swzw2(int x) {      // bit-reverse of bits 1..3 o
     return ((u & 1) << 2) | (u & 2) | (u >> 2);
 }
 
-// Issue the LDS-DMA loads of one 256-pixel tile (P rows then Q halo rows) into `sb`.
-template <int TWS>
-__device__ __forceinline__ void wg2_issue(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
-                                          const int (&pdesc)[4], const int (&qdesc)[6], int wave,
-                                          int tile_x, int tile_y, int n_img, char* sb) {
+// LDS-DMA loads of one 256-pixel tile (P rows then Q halo rows) into `sb`: piece IT of this wave (0..3: P, 4..9: Q).
+// A CU takes ~25 cycles per 1 KB piece; with all 8 waves issuing their ten pieces at the top of a tile that was ~2,100
+// cycles per tile in which no MFMA ran (cycle stamps, scripts/wgrad2_stamps.py), so the pieces are issued one per
+// k-step behind the second MFMA of k-steps 0..9 instead (wg2_kstep), where the other wave of the SIMD covers them.
+template <int TWS, int IT>
+__device__ __forceinline__ void wg2_issue_piece(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
+                                                const int (&pdesc)[4], const int (&qdesc)[6], int wave,
+                                                int tile_x, int tile_y, int n_img, char* sb) {
     constexpr int TW = 1 << TWS, TH = 256 / TW;
     constexpr int QROWS = 352, PBYTES = 256 * 128;
     const int H = g.H, W = g.W;
     const int y0 = tile_y * TH, x0 = tile_x * TW;
-    const __bf16* pimg = pg + (long long)n_img * g.p_img_stride;
-    const __bf16* qimg = qg + (long long)n_img * g.q_img_stride;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    if constexpr (IT < 4) {
+        constexpr int it = IT;
+        const __bf16* pimg = pg + (long long)n_img * g.p_img_stride;
         const int d = pdesc[it];
         const int gy = y0 + (d & 0xff) - 1, gx = x0 + ((d >> 8) & 0xff) - 1;
         const bool ok = gy < H && gx < W;
         const __bf16* src = ok ? pimg + (long long)(gy * W + gx) * g.ldp + (d >> 24) * 8
                                : reinterpret_cast<const __bf16*>(fea_zero_line);
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sb + (it * 8 + wave) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < 6; ++it) {
+    } else {
+        constexpr int it = IT - 4;
         if (it * 8 + wave < QROWS / 8) {
+            const __bf16* qimg = qg + (long long)n_img * g.q_img_stride;
             const int d = qdesc[it];
             const int gy = y0 + (d & 0xff) - 1, gx = x0 + ((d >> 8) & 0xff) - 1;
             const bool ok = !((d >> 16) & 1) && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -71,6 +75,12 @@ __device__ __forceinline__ void wg2_issue(const Wgrad2Args& g, const __bf16* pg,
             __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sb + PBYTES + (it * 8 + wave) * 1024), 16, 0, 0);
         }
     }
+}
+template <int TWS>
+__device__ __forceinline__ void wg2_issue(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
+                                          const int (&pdesc)[4], const int (&qdesc)[6], int wave,
+                                          int tile_x, int tile_y, int n_img, char* sb) {
+    sfor<0, 10>([&](auto ic) { wg2_issue_piece<TWS, decltype(ic)::value>(g, pg, qg, pdesc, qdesc, wave, tile_x, tile_y, n_img, sb); });
 }
 
 // Transposing LDS read issued as inline asm: hipcc neither reorders it nor
@@ -110,26 +120,59 @@ __device__ __forceinline__ void wg2_read(Wg2Frag<NT>& f, const uint32_t (&pa)[(1
     }
 }
 
-template <int TWS, int TAP0, int NT, int S>
-__device__ __forceinline__ void wg2_kstep(Wg2Frag<NT>& cur, Wg2Frag<NT>& nxt, const uint32_t (&pa)[(1 << TWS) / 16][2],
-                                          const uint32_t (&qa)[(1 << TWS) / 16][2][3], f32x16 (&acc)[NT]) {
+// k-step S: its fragments are in `cur`, those of S + 1 are in flight into `nxt` (issued during S - 1), and the reads of
+// S + 2 are issued into `far` between the MFMAs of this step: an LDS read has two k-steps (>= 256 cycles of MFMA) to
+// return.  With one step of distance (round 1) a wave alone reached 63 cycles per MFMA, i.e. every k-step exposed ~150
+// cycles of LDS latency, and the second wave of the SIMD did not fill them (cycle stamps, scripts/wgrad2_stamps.py).
+#ifdef WG2_STAMPS
+#define WG2_PH_PARAM , unsigned long long (&ph)[6], unsigned long long& tprev
+#define WG2_PH_ARG , ph, tprev
+#define WSTAMP(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[k] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define WG2_PH_PARAM
+#define WG2_PH_ARG
+#define WSTAMP(k) do {} while (0)
+#endif
+template <int TWS, int TAP0, int NT, int S, typename PieceFn>
+__device__ __forceinline__ void wg2_kstep(Wg2Frag<NT>& cur, Wg2Frag<NT>& nxt, Wg2Frag<NT>& far, const uint32_t (&pa)[(1 << TWS) / 16][2],
+                                          const uint32_t (&qa)[(1 << TWS) / 16][2][3], f32x16 (&acc)[NT], PieceFn&& piece WG2_PH_PARAM) {
+    if constexpr (S == 8) WSTAMP(4);
     constexpr int NSTEP = 256 / 16, NRD = 2 + 2 * NT;
-    constexpr bool more = S + 1 < NSTEP;
+#ifndef WG2_DEPTH
+#define WG2_DEPTH 1
+#endif
+    constexpr int D = WG2_DEPTH;                       // k-steps of read-ahead (1 or 2)
+    constexpr bool more1 = S + 1 < NSTEP, more2 = S + D < NSTEP;
     sfor<0, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        constexpr int issued = more ? wg2_start<NT>(t) : 0;          // next-step reads issued so far
-        if constexpr (t == 0) wg2_wait<NRD - 4 + issued>(cur.a[0], cur.a[1], cur.b[0][0], cur.b[0][1]);
-        else                  wg2_wait<NRD - (4 + 2 * t) + issued>(cur.b[t][0], cur.b[t][1]);
+        // reads in flight behind the ones this MFMA needs: the rest of this step's, all of step S + 1, and step S + 2 so far
+        constexpr int behind = (D == 2 && more1 ? NRD : 0) + (more2 ? wg2_start<NT>(t) : 0);
+        // (lgkmcnt is a 4-bit counter: at most 15 can be named, and a wave cannot have more LDS operations in flight)
+        constexpr int n0 = NRD - 4 + behind, nt = NRD - (4 + 2 * t) + behind;
+        if constexpr (t == 0) wg2_wait<(n0 < 15 ? n0 : 15)>(cur.a[0], cur.a[1], cur.b[0][0], cur.b[0][1]);
+        else                  wg2_wait<(nt < 15 ? nt : 15)>(cur.b[t][0], cur.b[t][1]);
         const u32x4 af = {cur.a[0].x, cur.a[0].y, cur.a[1].x, cur.a[1].y};
         const u32x4 bf = {cur.b[t][0].x, cur.b[t][0].y, cur.b[t][1].x, cur.b[t][1].y};
         mma16(acc[t], af, bf, (const __bf16*)nullptr);
-        if constexpr (more) {
+        if constexpr (more2) {
             sfor<0, wg2_cnt<NT>(t)>([&](auto rc) {
-                wg2_read<TWS, TAP0, NT, S + 1, wg2_start<NT>(t) + decltype(rc)::value>(nxt, pa, qa);
+                wg2_read<TWS, TAP0, NT, S + D, wg2_start<NT>(t) + decltype(rc)::value>(D == 2 ? far : nxt, pa, qa);
             });
         }
+#ifndef WG2_PPS
+#define WG2_PPS 1
+#endif
+        // the ten LDS-DMA pieces of the next tile: WG2_PPS per k-step, behind the MFMAs of taps 1 (and 3)
+        if constexpr (WG2_PPS == 1) { if constexpr (t == 1 && S < 10) piece(std::integral_constant<int, S>{}); }
+        else {
+            if constexpr (t == 1 && S < 5) piece(std::integral_constant<int, 2 * S>{});
+            if constexpr (t == 3 && S < 5) piece(std::integral_constant<int, 2 * S + 1>{});
+        }
     });
-    if constexpr (more) wg2_kstep<TWS, TAP0, NT, S + 1>(nxt, cur, pa, qa, acc);
+    if constexpr (more1) {
+        if constexpr (D == 2) wg2_kstep<TWS, TAP0, NT, S + 1>(nxt, far, cur, pa, qa, acc, piece WG2_PH_ARG);
+        else                  wg2_kstep<TWS, TAP0, NT, S + 1>(nxt, cur, far, pa, qa, acc, piece WG2_PH_ARG);
+    }
 }
 
 // One pipeline step: start the LDS-DMA loads of `next_tile` into the other
@@ -142,9 +185,12 @@ __device__ __forceinline__ void wg2_step(const Wgrad2Args& g, const __bf16* pg, 
                                          const int (&pdesc)[4], const int (&qdesc)[6], int wave, bool has_next, int ntx, int nty, int nn,
                                          char* dma, uint32_t rd,
                                          const int (&pcol)[(1 << TWS) / 16][2], const int (&qcol)[(1 << TWS) / 16][2][3],
-                                         f32x16 (&acc)[NT]) {
+                                         f32x16 (&acc)[NT] WG2_PH_PARAM) {
     constexpr int XSEG = (1 << TWS) / 16, PBYTES = 256 * 128;
-    if (has_next) wg2_issue<TWS>(g, pg, qg, pdesc, qdesc, wave, ntx, nty, nn, dma);
+    auto piece = [&](auto ic) {
+        if (has_next) wg2_issue_piece<TWS, decltype(ic)::value>(g, pg, qg, pdesc, qdesc, wave, ntx, nty, nn, dma);
+    };
+    WSTAMP(2);
     uint32_t pa[XSEG][2], qa[XSEG][2][3];
 #pragma unroll
     for (int xs = 0; xs < XSEG; ++xs)
@@ -154,9 +200,10 @@ __device__ __forceinline__ void wg2_step(const Wgrad2Args& g, const __bf16* pg, 
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) qa[xs][t][dx] = rd + PBYTES + qcol[xs][t][dx];
         }
-    Wg2Frag<NT> f0, f1;
+    Wg2Frag<NT> f0, f1, f2;
     sfor<0, 2 + 2 * NT>([&](auto rc) { wg2_read<TWS, TAP0, NT, 0, decltype(rc)::value>(f0, pa, qa); });
-    wg2_kstep<TWS, TAP0, NT, 0>(f0, f1, pa, qa, acc);
+    if constexpr (WG2_DEPTH == 2) sfor<0, 2 + 2 * NT>([&](auto rc) { wg2_read<TWS, TAP0, NT, 1, decltype(rc)::value>(f1, pa, qa); });
+    wg2_kstep<TWS, TAP0, NT, 0>(f0, f1, f2, pa, qa, acc, piece WG2_PH_ARG);
 }
 
 // Tile loop + epilogue staging for one wave group (taps TAP0 .. TAP0+NT-1).
@@ -179,14 +226,24 @@ __device__ __forceinline__ void wg2_run(const Wgrad2Args& g, const __bf16* pg, c
         ntx = tt % g.tiles_x; tt /= g.tiles_x;
         nty = tt % g.tiles_y; nn = tt / g.tiles_y;
     }
+#ifdef WG2_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int stage = (tile - t_begin) & 1;
         if (++ntx == g.tiles_x) { ntx = 0; if (++nty == g.tiles_y) { nty = 0; ++nn; } }
+        WSTAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WSTAMP(0);
         __syncthreads();                 // this wave's LDS-DMA has landed; barrier: tile complete, other stage free
+        WSTAMP(1);
         wg2_step<TWS, TAP0, NT>(g, pg, qg, pdesc, qdesc, wave, tile + 1 < t_end, ntx, nty, nn,
-                                smem + (stage ^ 1) * STAGE, lds_base + stage * STAGE, pcol, qcol, acc);
+                                smem + (stage ^ 1) * STAGE, lds_base + stage * STAGE, pcol, qcol, acc WG2_PH_ARG);
+        WSTAMP(5);
     }
+#ifdef WG2_STAMPS
+    if ((threadIdx.x & 63) == 0 && g.dbg) for (int k = 0; k < 6; ++k) g.dbg[(blockIdx.x * 8 + wave) * 6 + k] = ph[k];
+#endif
     __syncthreads();                     // every wave is done reading the stages
     float* ot = reinterpret_cast<float*>(smem);       // [64 m][64 n][9]
 #pragma unroll
@@ -270,6 +327,10 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args g) {
         wg2_issue<TWS>(g, pg, qg, pdesc, qdesc, wave, tx, tt % g.tiles_y, tt / g.tiles_y, smem);
     }
     // waves 0-3 take taps 0..4, waves 4-7 taps 5..8: every SIMD hosts one wave of each group
+#ifndef WG2_PRIO
+#define WG2_PRIO 1
+#endif
+    if (WG2_PRIO && kg == 1) __builtin_amdgcn_s_setprio(WG2_PRIO);
     if (kg == 0) wg2_run<TWS, 0, 5>(g, pg, qg, pdesc, qdesc, wave, t_begin, t_end, smem, pcol, qcol, wa * 32, wb * 32 + r, h);
     else         wg2_run<TWS, 5, 4>(g, pg, qg, pdesc, qdesc, wave, t_begin, t_end, smem, pcol, qcol, wa * 32, wb * 32 + r, h);
     __syncthreads();
@@ -332,6 +393,9 @@ int fea_wgrad2_launch(const void* dy, int lddy, const void* x, int ldx, float* d
     a.ldp = lddy; a.ldq = ldx; a.H = H; a.W = W; a.M = M; a.Nn = Nn;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
     a.nmt = p.nmt; a.nnt = p.nnt;
+#ifdef WG2_STAMPS
+    a.dbg = getenv("WG2_DBG_PTR") ? (unsigned long long*)strtoull(getenv("WG2_DBG_PTR"), nullptr, 0) : nullptr;
+#endif
     dim3 grid((unsigned)(p.nmt * p.nnt * p.splits)), block(512);
     if (p.tws == 5) hipLaunchKernelGGL((wgrad2_kernel<5>), grid, block, 0, s, a);
     else            hipLaunchKernelGGL((wgrad2_kernel<4>), grid, block, 0, s, a);
