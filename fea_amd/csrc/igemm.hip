@@ -618,11 +618,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
         if constexpr (EPI == 2) {
             // thread -> fixed channel chunk c = tid % CPR, pixels tid / CPR + i * (256 / CPR)
             const int c = tid % CPR;
-            float csc[8], csh[8], cmu[8], cis[8], a0[8], a1[8];
+            // 7 VALU per element: sum g and sum g*y are accumulated, sum g*xhat = invstd * (sum g*y - mean * sum g) is formed
+            // once per tile and channel at the end (as in conv_p.hip); relu'(bn(y)) = [y*scale + shift > 0] needs no max
+            float csc[8], csh[8], a0[8], a1[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ch = cout0 + c * 8 + j;
-                csc[j] = g.bn_scale[ch]; csh[j] = g.bn_shift[ch]; cmu[j] = g.bn_mean[ch]; cis[j] = g.bn_invstd[ch];
+                csc[j] = g.bn_scale[ch]; csh[j] = g.bn_shift[ch];
                 a0[j] = 0.f; a1[j] = 0.f;
             }
             const T* __restrict__ yb = (const T*)g.ybn + (long long)n_img * H * W * g.ldybn + cout0 + c * 8;
@@ -647,9 +649,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float yf = (float)yy[j];
-                            const float act = fmaxf(__builtin_fmaf(yf, csc[j], csh[j]), 0.f);   // == bn_act (elementwise.hip)
-                            const float gg = act > 0.f ? (float)dv[j] : 0.f;
-                            a0[j] += gg; a1[j] += gg * ((yf - cmu[j]) * cis[j]);
+                            const float gg = __builtin_fmaf(yf, csc[j], csh[j]) > 0.f ? (float)dv[j] : 0.f;   // bn_act(y) > 0 (elementwise.hip)
+                            a0[j] += gg; a1[j] = __builtin_fmaf(gg, yf, a1[j]);
                         }
                     }
                 }
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
                 for (int w_ = 0; w_ < 4; ++w_) { s0 += st[(w_ * BN + tid) * 2]; s1 += st[(w_ * BN + tid) * 2 + 1]; }
                 float* dst = g.red_part + ((long long)ptile * g.Cout + cout0 + tid) * 2;
-                dst[0] = s0; dst[1] = s1;
+                dst[0] = s0; dst[1] = g.bn_invstd[cout0 + tid] * (s1 - g.bn_mean[cout0 + tid] * s0);
             }
         } else {
 #pragma unroll
