@@ -30,6 +30,7 @@
 // Reference layers served: nn.Conv2d(ci,co,3,padding=1) models.py:28,31 (fwd and
 // dgrad), nn.ConvTranspose2d(ci,co,2,stride=2) models.py:15-21 (fwd, bwd-data).
 #include "common.h"
+#include <stdlib.h>
 
 #ifndef EPI2_GRP
 #define EPI2_GRP 4          // y loads in flight per thread in the fused BatchNorm-backward epilogue
@@ -51,7 +52,13 @@ struct IgemmArgs {
     float* red_part;   // [pixel tile][Cout][2]
     // EPI 3: optional 2x2 max-pool of the activated output, [N][H/2][W/2] pixels, ldpool apart
     void* pool; int ldpool;
+    unsigned long long* dbg;     // IG_STAMPS builds only: per-wave phase cycle sums [workgroup][wave][6]
 };
+#ifdef IG_STAMPS
+#define ISTAMP(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); iph[k] += tn_ - itprev; itprev = tn_; } while (0)
+#else
+#define ISTAMP(k) do {} while (0)
+#endif
 
 // XOR applied to a row's 16-byte chunk index.  A ds_read_b128 is served in groups of 16 lanes = 16 consecutive rows, 8 of them
 // reading chunk q and 8 chunk q ^ 1 (MI355X_MICROARCH.md, LDS table): bit 0 of the chunk is left alone so the two subsets never
@@ -482,11 +489,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
         }
     } else if (MODE == 0 && BF) {
         const int HW2 = TW + 2;
+#ifdef IG_STAMPS
+        unsigned long long iph[6] = {0, 0, 0, 0, 0, 0}, itprev = __builtin_amdgcn_s_memtime();
+#endif
         for (int ch = 0; ch < nchunks; ++ch) {
+            ISTAMP(5);
             __syncthreads();                       // previous chunk fully consumed
+            ISTAMP(0);
             stage_W(ch * 9, 0);
             stage_A(ch, 0);
+            ISTAMP(1);
             __syncthreads();                       // (drains the LDS-DMA: vmcnt(0) before the barrier)
+            ISTAMP(2);
 #pragma unroll
             for (int m = 0; m < 3; ++m) rd128(ArC[m], a_addr16(m, 0));
 #pragma unroll 1
@@ -496,9 +510,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
                 const int dy = tap / 3, dx = tap - dy * 3;
                 const int tn = tap == 8 ? 0 : tap + 1, dyn = tn / 3, dxn = tn - dyn * 3;   // (after tap 8: a harmless look-ahead)
                 compute_cont(dy * HW2 + dx, dyn * HW2 + dxn, tap & 1, [&]() {});
+                ISTAMP(3);
                 if (tap < 8) __syncthreads();
+                ISTAMP(4);
             }
         }
+#ifdef IG_STAMPS
+        if (lane == 0 && g.dbg) for (int k = 0; k < 6; ++k) atomicAdd(&g.dbg[(wave) * 6 + k], iph[k]);
+#endif
     } else if (MODE == 0) {
         const int HW2 = TW + 2;
         for (int ch = 0; ch < nchunks; ++ch) {
@@ -801,6 +820,9 @@ static int launch_igemm(IgemmArgs& a, int N, hipStream_t s) {
     const long long nblk = (long long)N * a.tiles_x * a.tiles_y * a.nct;
     FEA_CHECK(nblk > 0 && nblk < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "igemm: grid of %lld blocks", nblk);
     dim3 grid((unsigned)nblk), block(256);
+#ifdef IG_STAMPS
+    a.dbg = getenv("IG_DBG_PTR") ? (unsigned long long*)strtoull(getenv("IG_DBG_PTR"), nullptr, 0) : nullptr;
+#endif
     if (tws == 5) {
         if (bn128) hipLaunchKernelGGL((igemm_kernel<T, MODE, 128, EPI, 5>), grid, block, 0, s, a);
         else       hipLaunchKernelGGL((igemm_kernel<T, MODE, 64, EPI, 5>), grid, block, 0, s, a);
