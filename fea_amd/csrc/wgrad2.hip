@@ -46,14 +46,39 @@ __device__ __forceinline__ int swzw2(int x) {      // bit-reverse of bits 1..3 o
 // A CU takes ~25 cycles per 1 KB piece; with all 8 waves issuing their ten pieces at the top of a tile that was ~2,100
 // cycles per tile in which no MFMA ran (cycle stamps, scripts/wgrad2_stamps.py), so the pieces are issued one per
 // k-step behind the second MFMA of k-steps 0..9 instead (wg2_kstep), where the other wave of the SIMD covers them.
-template <int TWS, int IT>
+//
+// FAST (whole tiles only, images below 2 GB): pdesc / qdesc hold each lane's byte offset from the tile origin, the source is
+// a buffer descriptor of ONE image and a lane that must read zero padding (halo outside the image: the piece's 5 flag bits
+// in qfl, masked by the tile's edge bits) gets an out-of-range offset, for which the hardware returns 0 -- 1 VALU per
+// P piece and 4 per Q piece instead of ~20 (64-bit address arithmetic and selects): the issue sits in the MFMA stream.
+template <int TWS, int IT, bool FAST>
 __device__ __forceinline__ void wg2_issue_piece(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
-                                                const int (&pdesc)[4], const int (&qdesc)[6], int wave,
+                                                const int (&pdesc)[4], const int (&qdesc)[6], unsigned qfl, int wave,
                                                 int tile_x, int tile_y, int n_img, char* sb) {
     constexpr int TW = 1 << TWS, TH = 256 / TW;
     constexpr int QROWS = 352, PBYTES = 256 * 128;
     const int H = g.H, W = g.W;
     const int y0 = tile_y * TH, x0 = tile_x * TW;
+    if constexpr (FAST) {
+        if constexpr (IT < 4) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(pg + (long long)n_img * g.p_img_stride), 0,
+                                                                                (int)(g.p_img_stride * 2), 0x00020000);
+            const int voff = (y0 * W + x0) * g.ldp * 2 + pdesc[IT];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(sb + (IT * 8 + wave) * 1024), 16, voff, 0, 0, 0);
+        } else {
+            constexpr int it = IT - 4;
+            if (it * 8 + wave < QROWS / 8) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(qg + (long long)n_img * g.q_img_stride), 0,
+                                                                                    (int)(g.q_img_stride * 2), 0x00020000);
+                const unsigned edge = (tile_y == 0 ? 1u : 0u) | (tile_y == g.tiles_y - 1 ? 2u : 0u) | (tile_x == 0 ? 4u : 0u) |
+                                      (tile_x == g.tiles_x - 1 ? 8u : 0u) | 16u;
+                const unsigned f = (qfl >> (5 * it)) & edge & 31u;
+                const int voff = f ? (int)0xfffffff0u : (y0 * W + x0) * g.ldq * 2 + qdesc[it];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(sb + PBYTES + (it * 8 + wave) * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+        return;
+    }
     if constexpr (IT < 4) {
         constexpr int it = IT;
         const __bf16* pimg = pg + (long long)n_img * g.p_img_stride;
@@ -76,11 +101,11 @@ __device__ __forceinline__ void wg2_issue_piece(const Wgrad2Args& g, const __bf1
         }
     }
 }
-template <int TWS>
+template <int TWS, bool FAST>
 __device__ __forceinline__ void wg2_issue(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
-                                          const int (&pdesc)[4], const int (&qdesc)[6], int wave,
+                                          const int (&pdesc)[4], const int (&qdesc)[6], unsigned qfl, int wave,
                                           int tile_x, int tile_y, int n_img, char* sb) {
-    sfor<0, 10>([&](auto ic) { wg2_issue_piece<TWS, decltype(ic)::value>(g, pg, qg, pdesc, qdesc, wave, tile_x, tile_y, n_img, sb); });
+    sfor<0, 10>([&](auto ic) { wg2_issue_piece<TWS, decltype(ic)::value, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, tile_x, tile_y, n_img, sb); });
 }
 
 // Transposing LDS read issued as inline asm: hipcc neither reorders it nor
@@ -180,15 +205,15 @@ __device__ __forceinline__ void wg2_kstep(Wg2Frag<NT>& cur, Wg2Frag<NT>& nxt, Wg
 // TAP0 .. TAP0+NT-1.  The sixteen 16-pixel k-steps are fully unrolled and
 // software-pipelined by hand: the fragments of step s+1 are read from LDS
 // (inline asm) between the MFMAs of step s and retired by counted lgkmcnt.
-template <int TWS, int TAP0, int NT>
+template <int TWS, int TAP0, int NT, bool FAST>
 __device__ __forceinline__ void wg2_step(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
-                                         const int (&pdesc)[4], const int (&qdesc)[6], int wave, bool has_next, int ntx, int nty, int nn,
+                                         const int (&pdesc)[4], const int (&qdesc)[6], unsigned qfl, int wave, bool has_next, int ntx, int nty, int nn,
                                          char* dma, uint32_t rd,
                                          const int (&pcol)[(1 << TWS) / 16][2], const int (&qcol)[(1 << TWS) / 16][2][3],
                                          f32x16 (&acc)[NT] WG2_PH_PARAM) {
     constexpr int XSEG = (1 << TWS) / 16, PBYTES = 256 * 128;
     auto piece = [&](auto ic) {
-        if (has_next) wg2_issue_piece<TWS, decltype(ic)::value>(g, pg, qg, pdesc, qdesc, wave, ntx, nty, nn, dma);
+        if (has_next) wg2_issue_piece<TWS, decltype(ic)::value, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, ntx, nty, nn, dma);
     };
     WSTAMP(2);
     uint32_t pa[XSEG][2], qa[XSEG][2][3];
@@ -207,9 +232,9 @@ __device__ __forceinline__ void wg2_step(const Wgrad2Args& g, const __bf16* pg, 
 }
 
 // Tile loop + epilogue staging for one wave group (taps TAP0 .. TAP0+NT-1).
-template <int TWS, int TAP0, int NT>
+template <int TWS, int TAP0, int NT, bool FAST>
 __device__ __forceinline__ void wg2_run(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
-                                        const int (&pdesc)[4], const int (&qdesc)[6], int wave, int t_begin, int t_end,
+                                        const int (&pdesc)[4], const int (&qdesc)[6], unsigned qfl, int wave, int t_begin, int t_end,
                                         char* smem, const int (&pcol)[(1 << TWS) / 16][2], const int (&qcol)[(1 << TWS) / 16][2][3],
                                         int orow, int ocol, int h) {
     constexpr int STAGE = (256 + 352) * 128;
@@ -237,7 +262,7 @@ __device__ __forceinline__ void wg2_run(const Wgrad2Args& g, const __bf16* pg, c
         WSTAMP(0);
         __syncthreads();                 // this wave's LDS-DMA has landed; barrier: tile complete, other stage free
         WSTAMP(1);
-        wg2_step<TWS, TAP0, NT>(g, pg, qg, pdesc, qdesc, wave, tile + 1 < t_end, ntx, nty, nn,
+        wg2_step<TWS, TAP0, NT, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, tile + 1 < t_end, ntx, nty, nn,
                                 smem + (stage ^ 1) * STAGE, lds_base + stage * STAGE, pcol, qcol, acc WG2_PH_ARG);
         WSTAMP(5);
     }
@@ -255,7 +280,7 @@ __device__ __forceinline__ void wg2_run(const Wgrad2Args& g, const __bf16* pg, c
         }
 }
 
-template <int TWS>
+template <int TWS, bool FAST>
 __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args g) {
     constexpr int TW = 1 << TWS, TH = 256 / TW, HW2 = TW + 2;
     constexpr int QROWS = 352;                       // >= (TH+2)*HW2 (340 / 324), multiple of 8
@@ -298,21 +323,28 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args g) {
 
     // ---- LDS-DMA descriptors: instruction it of this wave moves 8 rows ------
     // packed: (ry+1) | (rx+1) << 8 | invalid << 16 | source chunk << 24
+    // FAST: byte offsets from the tile origin instead, and 5 flag bits per Q piece (top, bottom, left, right halo line, padding row)
     int pdesc[NPI], qdesc[NQI];
+    unsigned qfl = 0;
     {
         const int rsub = lane >> 3, cpos = lane & 7;
 #pragma unroll
         for (int it = 0; it < NPI; ++it) {
             const int row = (it * 8 + wave) * 8 + rsub;
             const int ty = row >> TWS, tx = row & (TW - 1);
-            pdesc[it] = (ty + 1) | ((tx + 1) << 8) | ((cpos ^ swzw2(tx)) << 24);
+            if constexpr (FAST) pdesc[it] = (ty * g.W + tx) * g.ldp * 2 + ((cpos ^ swzw2(tx)) << 4);
+            else pdesc[it] = (ty + 1) | ((tx + 1) << 8) | ((cpos ^ swzw2(tx)) << 24);
         }
 #pragma unroll
         for (int it = 0; it < NQI; ++it) {
             const int row = (it * 8 + wave) * 8 + rsub;
             const int hy = row / HW2, hx = row - hy * HW2;
             const int inval = hy >= TH + 2 ? 1 : 0;
-            qdesc[it] = hy | (hx << 8) | (inval << 16) | ((cpos ^ swzw2(hx)) << 24);   // ry = hy-1, rx = hx-1
+            if constexpr (FAST) {
+                qdesc[it] = ((hy - 1) * g.W + (hx - 1)) * g.ldq * 2 + ((cpos ^ swzw2(hx)) << 4);
+                const unsigned f = (hy == 0 ? 1u : 0u) | (hy == TH + 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == TW + 1 ? 8u : 0u) | (inval ? 16u : 0u);
+                qfl |= f << (5 * it);
+            } else qdesc[it] = hy | (hx << 8) | (inval << 16) | ((cpos ^ swzw2(hx)) << 24);   // ry = hy-1, rx = hx-1
         }
     }
 
@@ -324,15 +356,15 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args g) {
     if (t_begin < t_end) {
         int tt = t_begin;
         const int tx = tt % g.tiles_x; tt /= g.tiles_x;
-        wg2_issue<TWS>(g, pg, qg, pdesc, qdesc, wave, tx, tt % g.tiles_y, tt / g.tiles_y, smem);
+        wg2_issue<TWS, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, tx, tt % g.tiles_y, tt / g.tiles_y, smem);
     }
     // waves 0-3 take taps 0..4, waves 4-7 taps 5..8: every SIMD hosts one wave of each group
 #ifndef WG2_PRIO
 #define WG2_PRIO 1
 #endif
     if (WG2_PRIO && kg == 1) __builtin_amdgcn_s_setprio(WG2_PRIO);
-    if (kg == 0) wg2_run<TWS, 0, 5>(g, pg, qg, pdesc, qdesc, wave, t_begin, t_end, smem, pcol, qcol, wa * 32, wb * 32 + r, h);
-    else         wg2_run<TWS, 5, 4>(g, pg, qg, pdesc, qdesc, wave, t_begin, t_end, smem, pcol, qcol, wa * 32, wb * 32 + r, h);
+    if (kg == 0) wg2_run<TWS, 0, 5, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, t_begin, t_end, smem, pcol, qcol, wa * 32, wb * 32 + r, h);
+    else         wg2_run<TWS, 5, 4, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, t_begin, t_end, smem, pcol, qcol, wa * 32, wb * 32 + r, h);
     __syncthreads();
     const float* ot = reinterpret_cast<const float*>(smem);
     float* dst = g.out + (long long)split * g.out_split_stride + ((long long)m0 * g.Nn + n0) * 9;
@@ -397,8 +429,11 @@ int fea_wgrad2_launch(const void* dy, int lddy, const void* x, int ldx, float* d
     a.dbg = getenv("WG2_DBG_PTR") ? (unsigned long long*)strtoull(getenv("WG2_DBG_PTR"), nullptr, 0) : nullptr;
 #endif
     dim3 grid((unsigned)(p.nmt * p.nnt * p.splits)), block(512);
-    if (p.tws == 5) hipLaunchKernelGGL((wgrad2_kernel<5>), grid, block, 0, s, a);
-    else            hipLaunchKernelGGL((wgrad2_kernel<4>), grid, block, 0, s, a);
+    // whole tiles and 32-bit in-image byte offsets: the LDS-DMA pieces take the buffer-descriptor form (wg2_issue_piece)
+    const int TWl = 1 << p.tws, THl = 256 / TWl;
+    const bool fast = H % THl == 0 && W % TWl == 0 && (long long)(H + 2) * W * lddy * 2 < (1ll << 31) && (long long)(H + 2) * W * ldx * 2 < (1ll << 31);
+    if (p.tws == 5) { if (fast) hipLaunchKernelGGL((wgrad2_kernel<5, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((wgrad2_kernel<5, false>), grid, block, 0, s, a); }
+    else            { if (fast) hipLaunchKernelGGL((wgrad2_kernel<4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((wgrad2_kernel<4, false>), grid, block, 0, s, a); }
     FEA_LAUNCH_CHECK();
     if (p.splits > 1) {
         const long long per4 = (long long)9 * M * Nn / 4;
