@@ -76,6 +76,48 @@ __device__ __forceinline__ void sfor(F&& f) {
 // (igemm.hip DB path, elementwise.hip pack_conv3x3_kernel).  One rule for both sides.
 __host__ __device__ inline bool fea_conv3x3_frag_pack(int gemm_n, int elem_bytes) { return elem_bytes == 2 && gemm_n % 128 != 0; }
 
+// Deterministic sum of the pixel-split slabs of the weight-gradient kernels: out[i] = sum over sp of slab[sp][i], i in float4
+// units.  With hundreds of splits and a small weight (64 -> 64: 256 splits of 147 KB) one thread per element is a chain of
+// 256 dependent strided loads on 36 workgroups: 0.62 ms for 38 MB.  Here SL lanes share an element: lane j adds splits
+// j, j + SL, ... into four independent partial sums, and the SL lane sums are then added in lane order through LDS -- a fixed
+// association for a given (splits, SL), so the result is bit-identical from run to run.
+template <int SL>
+static __global__ __launch_bounds__(256) void fea_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                                     int splits, long long per4) {
+    constexpr int EPB = 256 / SL;                       // float4 elements per block
+    const int e = threadIdx.x % EPB, j = threadIdx.x / EPB;
+    const long long i = (long long)blockIdx.x * EPB + e;
+    __shared__ f32x4 part[256];
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (i < per4) {
+        const f32x4* s = reinterpret_cast<const f32x4*>(slab) + i;
+        int sp = j;
+        for (; sp + 3 * SL < splits; sp += 4 * SL) {
+            a0 += s[(long long)sp * per4]; a1 += s[(long long)(sp + SL) * per4];
+            a2 += s[(long long)(sp + 2 * SL) * per4]; a3 += s[(long long)(sp + 3 * SL) * per4];
+        }
+        for (; sp < splits; sp += SL) a0 += s[(long long)sp * per4];
+    }
+    const f32x4 a = (a0 + a1) + (a2 + a3);
+    if constexpr (SL == 1) {
+        if (i < per4) reinterpret_cast<f32x4*>(out)[i] = a;
+    } else {
+        part[j * EPB + e] = a;
+        __syncthreads();
+        if (j == 0 && i < per4) {
+            f32x4 r = part[e];
+#pragma unroll
+            for (int k = 1; k < SL; ++k) r += part[k * EPB + e];
+            reinterpret_cast<f32x4*>(out)[i] = r;
+        }
+    }
+}
+static inline void fea_launch_slab_reduce(const float* slab, float* out, int splits, long long per4, hipStream_t s) {
+    if (splits >= 32)     hipLaunchKernelGGL((fea_slab_reduce_kernel<16>), dim3((unsigned)((per4 + 15) / 16)), dim3(256), 0, s, slab, out, splits, per4);
+    else if (splits >= 8) hipLaunchKernelGGL((fea_slab_reduce_kernel<4>), dim3((unsigned)((per4 + 63) / 64)), dim3(256), 0, s, slab, out, splits, per4);
+    else                  hipLaunchKernelGGL((fea_slab_reduce_kernel<1>), dim3((unsigned)((per4 + 255) / 256)), dim3(256), 0, s, slab, out, splits, per4);
+}
+
 // host side -----------------------------------------------------------------
 void fea_set_error(const char* fmt, ...);
 #define FEA_CHECK(cond, code, ...) do { if (!(cond)) { fea_set_error(__VA_ARGS__); return (code); } } while (0)

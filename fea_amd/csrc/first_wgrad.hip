@@ -170,13 +170,25 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstWgradArgs g
 // out[co][c][tap] = sum over splits of slab[split][co][tap*C + c]
 __global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                                  int splits, int Cout, int C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Cout * 9 * C) return;
-    const int tap = i % 9, c = (i / 9) % C, co = i / (9 * C);
-    const int n = tap * C + c;
+    // 16 lanes share an output element (lane j adds splits j, j + 16, ...), their sums are added in lane order: a fixed
+    // association, bit-identical from run to run, without a chain of `splits` dependent loads per thread
+    const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + e;
+    __shared__ float part[256];
     float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += slab[((long long)sp * Cout + co) * 64 + n];
-    out[i] = s;
+    if (i < Cout * 9 * C) {
+        const int tap = i % 9, c = (i / 9) % C, co = i / (9 * C);
+        const int n = tap * C + c;
+        for (int sp = j; sp < splits; sp += 16) s += slab[((long long)sp * Cout + co) * 64 + n];
+    }
+    part[j * 16 + e] = s;
+    __syncthreads();
+    if (j == 0 && i < Cout * 9 * C) {
+        float r = part[e];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) r += part[k * 16 + e];
+        out[i] = r;
+    }
 }
 
 struct FwPlan { int tiles_x, tiles_y, ntiles, splits, tiles_per_split; };
@@ -218,7 +230,7 @@ extern "C" int fea_conv3x3_first_wgrad(const void* dy, int lddy, const float* x,
     else        hipLaunchKernelGGL(first_wgrad_kernel<10240>, dim3((unsigned)p.splits, (unsigned)(Cout / 64)), dim3(256), 0, s, a);
     FEA_LAUNCH_CHECK();
     const int total = Cout * 9 * C;
-    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s,
                        (const float*)ws, dW, p.splits, Cout, C);
     FEA_LAUNCH_CHECK();
     return FEA_OK;

@@ -376,16 +376,6 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args g) {
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
-                                                            int splits, long long per4) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per4) return;
-    const f32x4* s = reinterpret_cast<const f32x4*>(slab);
-    f32x4 a = s[i];
-    for (int sp = 1; sp < splits; ++sp) a += s[sp * per4 + i];
-    reinterpret_cast<f32x4*>(out)[i] = a;
-}
-
 // ---------------------------------------------------------------------------
 struct Wgrad2Plan { int tws, tiles_x, tiles_y, ntiles, splits, tiles_per_split, nmt, nnt; };
 
@@ -437,8 +427,7 @@ int fea_wgrad2_launch(const void* dy, int lddy, const void* x, int ldx, float* d
     FEA_LAUNCH_CHECK();
     if (p.splits > 1) {
         const long long per4 = (long long)9 * M * Nn / 4;
-        hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3((unsigned)((per4 + 255) / 256)), dim3(256), 0, s,
-                           (const float*)ws, dW, p.splits, per4);
+        fea_launch_slab_reduce((const float*)ws, dW, p.splits, per4, s);
         FEA_LAUNCH_CHECK();
     }
     return FEA_OK;

@@ -12,7 +12,7 @@
 // ring (two tiles in flight: the op is latency-bound with one).  Wave w = (x half, tap) multiplies a 64 x 64 block: transposing LDS reads
 // (ds_read_b64_tr_b16) feed v_mfma_f32_32x32x16_bf16, reduction step = one 16-pixel tile row.
 // Workgroups write fp32 slabs in the parameter's own [ci][co][2][2] order; the slabs are
-// summed in a fixed order by wgrad2_reduce_kernel (deterministic).
+// summed in a fixed order by fea_slab_reduce_kernel (common.h; deterministic).
 #include "common.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -140,15 +140,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_up_kernel(const WgradUpArgs g) {
             }
 }
 
-__global__ __launch_bounds__(256) void wgrad_up_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
-                                                              int splits, long long per4) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per4) return;
-    const f32x4* s = reinterpret_cast<const f32x4*>(slab);
-    f32x4 a = s[i];
-    for (int sp = 1; sp < splits; ++sp) a += s[sp * per4 + i];
-    reinterpret_cast<f32x4*>(out)[i] = a;
-}
 
 struct WuPlan { int tiles_x, tiles_y, ntiles, splits, tiles_per_split, nmt, nnt; };
 static WuPlan wu_plan(int N, int H, int W, int Cin, int Cout) {
@@ -190,8 +181,7 @@ int fea_wgrad_up_launch(const void* x, int ldx, const void* dy, int lddy, float*
     FEA_LAUNCH_CHECK();
     if (p.splits > 1) {
         const long long per4 = (long long)Cin * Cout;
-        hipLaunchKernelGGL(wgrad_up_reduce_kernel, dim3((unsigned)((per4 + 255) / 256)), dim3(256), 0, s,
-                           (const float*)ws, dW, p.splits, per4);
+        fea_launch_slab_reduce((const float*)ws, dW, p.splits, per4, s);
         FEA_LAUNCH_CHECK();
     }
     return FEA_OK;
