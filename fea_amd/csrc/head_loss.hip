@@ -614,6 +614,249 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(const T* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// Head + loss fused, MFMA form (bf16 activations, H*W % 16 == 0, <= 8 classes): the same two passes as above, with both
+// small GEMMs of a 16-pixel tile on the matrix pipe instead of 8-lane dot products:
+//   logits^T[class][pixel] = W[class][k] x^T[k][pixel]        A = weight (rows = classes, padded to 16), B = 16 pixels
+//   da^T[ch][pixel]        = W^T[ch][class] d[class][pixel]   A = weight^T (four 16-channel row blocks), B = dlogits
+// The first product leaves lane (pixel = lane % 16, q = lane / 16) with classes 4q .. 4q+3 of its pixel in the four
+// accumulator registers; the second takes exactly that as its B operand when k-slot (q, j) of the MFMA stands for class
+// 4q + j (j < 4; slots 4..7 are zero on both sides) -- no lane exchange between the two.  The fp32 weight enters as
+// hi + lo bf16 pairs (two MFMAs), dlogits likewise (d_hi W_hi + d_lo W_hi + d_hi W_lo), so the results agree with the fp32
+// arithmetic of the separate kernels to ~2^-16 before the final bf16 rounding of da.  dW / db stay on the VALU: every lane
+// fetches the (<= 8) dlogits of its pixel from the two lanes that hold them and multiplies them into its 16 channels.
+__device__ __forceinline__ uint32_t hl_pack(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+    const f2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2_t));
+}
+__device__ __forceinline__ float hl_lo(float w) { return w - (float)(__bf16)w; }        // what bf16(w) leaves out
+
+struct HlFrag { u32x4 ah[2], al[2]; float bias[4]; };
+// GEMM 1 A operand: lane (row = class = lane % 16, q): k = q*8 + j  <->  input channel ks*32 + q*8 + j
+__device__ __forceinline__ void hl_weights(HlFrag& f, const float* __restrict__ w, const float* __restrict__ bias, int Ccls, int r16, int q) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = r16 < Ccls ? w[r16 * 64 + ks * 32 + q * 8 + j] : 0.f;
+        f.ah[ks] = u32x4{hl_pack(v[0], v[1]), hl_pack(v[2], v[3]), hl_pack(v[4], v[5]), hl_pack(v[6], v[7])};
+        f.al[ks] = u32x4{hl_pack(hl_lo(v[0]), hl_lo(v[1])), hl_pack(hl_lo(v[2]), hl_lo(v[3])),
+                         hl_pack(hl_lo(v[4]), hl_lo(v[5])), hl_pack(hl_lo(v[6]), hl_lo(v[7]))};
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f.bias[e] = 4 * q + e < Ccls ? bias[4 * q + e] : 0.f;
+}
+__device__ __forceinline__ f32x4 hl_logits(const HlFrag& f, const u32x4& x0, const u32x4& x1) {
+    f32x4 acc = {f.bias[0], f.bias[1], f.bias[2], f.bias[3]};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.ah[0]), __builtin_bit_cast(bf16x8, x0), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.al[0]), __builtin_bit_cast(bf16x8, x0), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.ah[1]), __builtin_bit_cast(bf16x8, x1), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.al[1]), __builtin_bit_cast(bf16x8, x1), acc, 0, 0, 0);
+    return acc;
+}
+
+// Loss terms on the hardware transcendentals (v_exp_f32 / v_rcp_f32 / v_log_f32, ~1 ulp each): only 6 of the 16 lanes of a
+// row hold real classes after the swapped product, so the libm sequences of loss_terms() (expf, log1pf, a division: ~80
+// instructions per element) made these kernels VALU-bound.  |log(1 + e) - log1p(e)| <= 6e-8 absolute per element.
+__device__ __forceinline__ void loss_terms_fast(float v, float tt, float& sb, float& si, float& sp, float& st) {
+    const float e = __expf(-fabsf(v));
+    const float r = __builtin_amdgcn_rcpf(1.f + e);
+    const float p = v >= 0.f ? r : e * r;
+    sb += fmaxf(v, 0.f) - v * tt + __logf(1.f + e);
+    si += p * tt; sp += p; st += tt;
+}
+
+__global__ __launch_bounds__(256) void head_loss_sums_mfma_kernel(const __bf16* __restrict__ a, int lda, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, const uint8_t* __restrict__ tgt,
+                                                                  float* __restrict__ logits, float* __restrict__ part,
+                                                                  long long ntile, long long HW, int Ccls) {
+    __shared__ float red[4][8][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    HlFrag f;
+    hl_weights(f, w, bias, Ccls, r16, q);
+    float sb[4] = {0.f, 0.f, 0.f, 0.f}, si[4] = {0.f, 0.f, 0.f, 0.f}, sp[4] = {0.f, 0.f, 0.f, 0.f}, st[4] = {0.f, 0.f, 0.f, 0.f};
+    // one tile of read-ahead: the loads of tile t + nw are issued before tile t is multiplied (the kernel is a stream: at
+    // 5 waves per SIMD and no read-ahead it waited for HBM most of the time)
+    const long long nw = (long long)gridDim.x * 4;
+    u32x4 x0, x1, y0, y1;
+    uint8_t tb[4], tn[4];
+    auto fetch = [&](long long t, u32x4& u0, u32x4& u1, uint8_t (&tt)[4]) {
+        const long long p0 = t * 16, n = p0 / HW, hw = p0 - n * HW;
+        const __bf16* xr = a + (p0 + r16) * lda + q * 8;
+        u0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr));
+        u1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr + 32));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tt[e] = 4 * q + e < Ccls ? tgt[(n * Ccls + 4 * q + e) * HW + hw + r16] : (uint8_t)0;
+    };
+    long long t = (long long)blockIdx.x * 4 + wv;
+    if (t < ntile) fetch(t, x0, x1, tb);
+    while (t < ntile) {
+        const long long t2 = t + nw;
+        if (t2 < ntile) fetch(t2, y0, y1, tn);
+        const long long p0 = t * 16, n = p0 / HW, hw = p0 - n * HW;
+        const f32x4 v = hl_logits(f, x0, x1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * q + e;
+            if (c < Ccls) {
+                if (logits) logits[(n * Ccls + c) * HW + hw + r16] = v[e];
+                loss_terms_fast(v[e], tb[e] ? 1.f : 0.f, sb[e], si[e], sp[e], st[e]);
+            }
+        }
+        x0 = y0; x1 = y1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tb[e] = tn[e];
+        t = t2;
+    }
+    // lanes with equal q hold the same four classes: sum over the 16 pixels lanes, then over the four waves
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float vals[4] = {sb[e], si[e], sp[e], st[e]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float x = vals[k];
+            x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
+            if (r16 == 0 && q < 2) red[wv][4 * q + e][k] = x;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < Ccls * 4) {
+        const int c = threadIdx.x >> 2, k = threadIdx.x & 3;
+        part[((long long)blockIdx.x * Ccls + c) * 4 + k] = red[0][c][k] + red[1][c][k] + red[2][c][k] + red[3][c][k];
+    }
+}
+
+template <int NC>                                  // classes the dW accumulators are sized for (6 or 8)
+__global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16* __restrict__ a, int lda, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, const uint8_t* __restrict__ tgt,
+                                                                    const double* __restrict__ sums, float* __restrict__ loss,
+                                                                    __bf16* __restrict__ da, int ldda, float* __restrict__ part,
+                                                                    float gscale, long long ntile, long long HW, int N, int Ccls) {
+    __shared__ float red[4][NC * 65];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const long long total = (long long)N * Ccls * HW;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss) {
+        double bce = 0.0, dice = 0.0;
+        for (int c = 0; c < Ccls; ++c) {
+            bce += sums[c * 4];
+            dice += (2.0 * sums[c * 4 + 1] + 1.0) / (sums[c * 4 + 2] + sums[c * 4 + 3] + 1.0);
+        }
+        loss[0] = (float)(bce / (double)total + 1.0 - dice / Ccls);
+    }
+    HlFrag f;
+    hl_weights(f, w, bias, Ccls, r16, q);
+    // GEMM 2 A operand, row block mb: lane (row = channel mb*16 + lane % 16, q): k-slot j < 4 <-> class 4q + j, slots 4..7 zero
+    u32x4 w2h[4], w2l[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = 4 * q + j < Ccls ? w[(4 * q + j) * 64 + mb * 16 + r16] : 0.f;
+        w2h[mb] = u32x4{hl_pack(v[0], v[1]), hl_pack(v[2], v[3]), 0u, 0u};
+        w2l[mb] = u32x4{hl_pack(hl_lo(v[0]), hl_lo(v[1])), hl_pack(hl_lo(v[2]), hl_lo(v[3])), 0u, 0u};
+    }
+    float cf0[4], cf1[4];                             // per class of this lane: 1/(S+1), (2I+1)/(S+1)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * q + e;
+        const double I = c < Ccls ? sums[c * 4 + 1] : 0.0, S = c < Ccls ? sums[c * 4 + 2] + sums[c * 4 + 3] : 0.0;
+        cf0[e] = (float)(1.0 / (S + 1.0));
+        cf1[e] = (float)((2.0 * I + 1.0) / (S + 1.0));
+    }
+    const float itot = 1.f / (float)total, ic = 1.f / (float)Ccls;
+    float gw[NC][16], gb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gw[c][j] = 0.f;
+
+    const long long nw = (long long)gridDim.x * 4;
+    u32x4 x0, x1, y0, y1;
+    uint8_t tb[4], tn[4];
+    auto fetch = [&](long long t, u32x4& u0, u32x4& u1, uint8_t (&tt)[4]) {
+        const long long p0 = t * 16, n = p0 / HW, hw = p0 - n * HW;
+        const __bf16* xr = a + (p0 + r16) * lda + q * 8;
+        u0 = *reinterpret_cast<const u32x4*>(xr);
+        u1 = *reinterpret_cast<const u32x4*>(xr + 32);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tt[e] = 4 * q + e < Ccls ? tgt[(n * Ccls + 4 * q + e) * HW + hw + r16] : (uint8_t)0;
+    };
+    long long t = (long long)blockIdx.x * 4 + wv;
+    if (t < ntile) fetch(t, x0, x1, tb);
+    while (t < ntile) {
+        const long long t2 = t + nw;
+        if (t2 < ntile) fetch(t2, y0, y1, tn);          // one tile of read-ahead (two waves per SIMD do not hide HBM latency)
+        const long long p0 = t * 16;
+        const f32x4 v = hl_logits(f, x0, x1);
+        float d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * q + e;
+            d[e] = 0.f;
+            if (c < Ccls) {
+                const float tt = tb[e] ? 1.f : 0.f;
+                const float ex = __expf(-fabsf(v[e]));
+                const float r = __builtin_amdgcn_rcpf(1.f + ex);
+                const float pr = v[e] >= 0.f ? r : ex * r;
+                const float ddice = (2.f * tt - cf1[e]) * cf0[e];
+                d[e] = ((pr - tt) * itot - ddice * pr * (1.f - pr) * ic) * gscale;
+                gb[e] += d[e];
+            }
+        }
+        // da = W^T d on the matrix pipe
+        const u32x4 bh = {hl_pack(d[0], d[1]), hl_pack(d[2], d[3]), 0u, 0u};
+        const u32x4 bl = {hl_pack(hl_lo(d[0]), hl_lo(d[1])), hl_pack(hl_lo(d[2]), hl_lo(d[3])), 0u, 0u};
+        __bf16* dr = da + (p0 + r16) * ldda + 4 * q;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2h[mb]), __builtin_bit_cast(bf16x8, bh), o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2h[mb]), __builtin_bit_cast(bf16x8, bl), o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2l[mb]), __builtin_bit_cast(bf16x8, bh), o, 0, 0, 0);
+            *reinterpret_cast<u32x2*>(dr + mb * 16) = u32x2{hl_pack(o[0], o[1]), hl_pack(o[2], o[3])};
+        }
+        // dW: the dlogits of this lane's pixel for every class (lanes (pixel, 0) and (pixel, 1) hold them) x its 16 channels
+        float xf[16];
+        {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, x0), b1 = __builtin_bit_cast(bf16x8, x1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { xf[j] = (float)b0[j]; xf[8 + j] = (float)b1[j]; }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c < Ccls) {                                  // (uniform)
+                const float dc = __shfl(d[c & 3], r16 + 16 * (c >> 2));
+#pragma unroll
+                for (int j = 0; j < 16; ++j) gw[c][j] = __builtin_fmaf(dc, xf[j], gw[c][j]);
+            }
+        }
+        x0 = y0; x1 = y1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tb[e] = tn[e];
+        t = t2;
+    }
+    // reduce over the 16 pixel lanes, then over the four waves; lane (0, q) owns channels q*8 .. +7 and 32 + q*8 .. +7
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float x = gw[c][j];
+            x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
+            if (r16 == 0) red[wv][c * 65 + (j >> 3) * 32 + q * 8 + (j & 7)] = x;
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = gb[e];
+        x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
+        if (r16 == 0 && 4 * q + e < NC) red[wv][(4 * q + e) * 65 + 64] = x;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Ccls * 65; i += 256)
+        part[(long long)blockIdx.x * (Ccls * 65) + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+// ---------------------------------------------------------------------------
 // fea_bce_dice_sums for callers that cannot allocate (HIP graph capture, tight serving / evaluation
 // loops, harnesses that forbid hipMalloc): the per-block partial sums live in a fixed device array of
 // this code object instead of a caller workspace.  Every GPU holds its own copy of the array at its
@@ -703,7 +946,8 @@ extern "C" int fea_head_loss_sums(const void* a, int lda, const float* w, const 
     const long long npix = (long long)N * H * W, HW = (long long)H * W;
     const int nblk = head_blocks(npix);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == FEA_BF16) hipLaunchKernelGGL((head_loss_sums_kernel<__bf16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, logits, part, npix / 4, HW, Ccls);
+    if (dtype == FEA_BF16 && HW % 16 == 0) hipLaunchKernelGGL(head_loss_sums_mfma_kernel, dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, logits, part, npix / 16, HW, Ccls);
+    else if (dtype == FEA_BF16) hipLaunchKernelGGL((head_loss_sums_kernel<__bf16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, logits, part, npix / 4, HW, Ccls);
     else if (dtype == FEA_F32) hipLaunchKernelGGL((head_loss_sums_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)a, lda, w, bias, target, logits, part, npix / 4, HW, Ccls);
     else { fea_set_error("%s: bad dtype", who); return FEA_E_BADARG; }
     FEA_LAUNCH_CHECK();
@@ -726,7 +970,9 @@ extern "C" int fea_head_loss_bwd(const void* a, int lda, const float* w, const f
     long long ppb = (npix + nblk - 1) / nblk;
     ppb = (ppb + 63) / 64 * 64;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == FEA_BF16) hipLaunchKernelGGL((head_loss_bwd_kernel<__bf16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, npix, HW, N, Ccls, ppb);
+    if (dtype == FEA_BF16 && HW % 16 == 0 && Ccls <= 6) hipLaunchKernelGGL(head_loss_bwd_mfma_kernel<6>, dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, npix / 16, HW, N, Ccls);
+    else if (dtype == FEA_BF16 && HW % 16 == 0) hipLaunchKernelGGL(head_loss_bwd_mfma_kernel<8>, dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, npix / 16, HW, N, Ccls);
+    else if (dtype == FEA_BF16) hipLaunchKernelGGL((head_loss_bwd_kernel<__bf16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, npix, HW, N, Ccls, ppb);
     else if (dtype == FEA_F32) hipLaunchKernelGGL((head_loss_bwd_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)a, lda, w, bias, target, sums, loss, (float*)da, ldda, part, gscale, npix, HW, N, Ccls, ppb);
     else { fea_set_error("%s: bad dtype", who); return FEA_E_BADARG; }
     FEA_LAUNCH_CHECK();

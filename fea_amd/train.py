@@ -110,9 +110,10 @@ class UNetTrainer:
         self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=cfg["num_epochs"], eta_min=1e-6)
         self.loss_ws = {}
         # Fused head + loss kernels (fea_head_loss_sums / _bwd: logits and dlogits stay in registers, 2 GB less HBM
-        # traffic per batch-64 step) are correct but SLOWER than the four separate kernels on MI355X (3.05 ms vs
-        # 2.3 ms per step: they are latency-bound) -- opt-in until that is fixed.
-        self.fuse_head_loss = os.environ.get("FEA_AMD_FUSE_HEAD_LOSS", "0") == "1"
+        # traffic per batch-64 step).  On by default where their matrix-pipe form applies (bf16, H*W % 16 == 0:
+        # 1.7 ms against 2.35 ms for the four separate kernels); the 8-lane VALU form of the other cases is slower than
+        # the separate kernels (3.05 ms) and stays opt-in.  FEA_AMD_FUSE_HEAD_LOSS=0 / 1 forces either.
+        self.fuse_head_loss = os.environ.get("FEA_AMD_FUSE_HEAD_LOSS")
         self.buckets = None
         self.distributed = distributed
         self._grads_bound = False
@@ -130,7 +131,10 @@ class UNetTrainer:
         """One optimisation step; returns the loss as a 1-element device tensor."""
         m = self.model
         m.train()
-        fused = self.fuse_head_loss and self.eng.fused_loss_supported(x.shape[2], x.shape[3])
+        fused = self.eng.fused_loss_supported(x.shape[2], x.shape[3]) and (
+            self.fuse_head_loss == "1" if self.fuse_head_loss in ("0", "1")
+            else bool(self.fuse_head_loss) if isinstance(self.fuse_head_loss, bool)
+            else (self.eng.dtype == torch.bfloat16 and (x.shape[2] * x.shape[3]) % 16 == 0))
         logits = self.eng.forward(x, True, head=not fused)
         if not self._grads_bound:
             self.eng._ensure_device(x)

@@ -599,16 +599,18 @@ def test_fused_head_loss_matches_the_separate_kernels(dt, shape):
     L.call("fea_head_loss_bwd", ap, 72, wd, bd, td, sums2, loss2, view_ptr(da2, 16), 80, hpart2, 1.0, n, h, w, 64, c, code, S())
     L.call("fea_head_bwd_finalize", hpart2, nblk, dW2, db2, 64, c, S())
     torch.cuda.synchronize()
-    if dt == torch.bfloat16:          # same kernel structure as fea_head_fwd's bf16 path: identical bits
+    mfma = dt == torch.bfloat16 and (h * w) % 16 == 0     # matrix-pipe form: fp32 weight as hi + lo bf16 (2^-16), other summation order
+    if dt == torch.bfloat16 and not mfma:  # same kernel structure as fea_head_fwd's bf16 path: identical bits
         assert torch.equal(lg2, logits), "the fused kernel's logits differ from fea_head_fwd's"
-    assert rel_l2(lg2.cpu(), logits.cpu()) < 1e-6
-    assert rel_l2(sums2.cpu(), sums.cpu()) < 1e-6
-    assert abs(loss2.item() - loss.item()) < 1e-6 * abs(loss.item())
+    tol = 2e-5 if mfma else 1e-6
+    assert rel_l2(lg2.cpu(), logits.cpu()) < tol, rel_l2(lg2.cpu(), logits.cpu())
+    assert rel_l2(sums2.cpu(), sums.cpu()) < tol
+    assert abs(loss2.item() - loss.item()) < tol * abs(loss.item())
     ref_loss = O.bce_dice_loss(logits.cpu(), tgt)
     assert abs(loss2.item() - ref_loss.item()) < 1e-5 * abs(ref_loss.item())
     check(da2[..., 16:80], from_nhwc(da, 64).permute(0, 2, 3, 1), dt, "fused head backward: da")
     assert torch.isnan(da2[..., :16].float()).all()
-    assert rel_l2(dW2.cpu(), dW.cpu()) < 1e-5 and rel_l2(db2.cpu(), db.cpu()) < 1e-5
+    assert rel_l2(dW2.cpu(), dW.cpu()) < (1e-4 if mfma else 1e-5) and rel_l2(db2.cpu(), db.cpu()) < (1e-4 if mfma else 1e-5)
 
 
 @pytest.mark.parametrize("shape", [(2, 6, 32, 48), (1, 1, 16, 16), (3, 6, 128, 96), (2, 3, 5, 7)])
