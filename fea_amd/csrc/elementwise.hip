@@ -291,11 +291,23 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const T* __restrict__
     const long long total = (long long)N * Ho * Wo * gpp;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int grp = (int)(i % gpp);
-    long long pix = i / gpp;
-    const int xo = (int)(pix % Wo); pix /= Wo;
-    const int yo = (int)(pix % Ho);
-    const int n = (int)(pix / Ho);
+    // 32-bit divisions where the item count allows (always, for this network): the 64-bit ones are ~100 VALU instructions
+    // each, per 16-byte item of a kernel that should only stream
+    int grp, xo, yo, n;
+    if (total < (1ll << 32)) {
+        const unsigned iu = (unsigned)i;
+        grp = (int)(iu % (unsigned)gpp);
+        unsigned pix = iu / (unsigned)gpp;
+        xo = (int)(pix % (unsigned)Wo); pix /= (unsigned)Wo;
+        yo = (int)(pix % (unsigned)Ho);
+        n = (int)(pix / (unsigned)Ho);
+    } else {
+        grp = (int)(i % gpp);
+        long long pix = i / gpp;
+        xo = (int)(pix % Wo); pix /= Wo;
+        yo = (int)(pix % Ho);
+        n = (int)(pix / Ho);
+    }
     float sc[V], sh[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) { sc[j] = scale[grp * V + j]; sh[j] = shift[grp * V + j]; }
@@ -374,13 +386,24 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const T* __restrict__ 
             const long long it = itb + (long long)u * slots;
             live[u] = it < it1;
             long long t = live[u] ? it : itb;
-            const int xo = (int)(t % Wo); t /= Wo;
-            const int yo = (int)(t % Ho);
-            const int n = (int)(t / Ho);
+            // without pooling the item index IS the pixel index; with it, 32-bit divisions where the count allows
+            int xo = 0, yo = 0, n = 0;
+            if constexpr (POOL) {
+                if (nitems < (1ll << 32)) {
+                    unsigned tu = (unsigned)t;
+                    xo = (int)(tu % (unsigned)Wo); tu /= (unsigned)Wo;
+                    yo = (int)(tu % (unsigned)Ho);
+                    n = (int)(tu / (unsigned)Ho);
+                } else {
+                    long long tl = t;
+                    xo = (int)(tl % Wo); tl /= Wo;
+                    yo = (int)(tl % Ho);
+                    n = (int)(tl / Ho);
+                }
+            }
 #pragma unroll
             for (int w4 = 0; w4 < NP; ++w4) {
-                pidx[u][w4] = POOL ? ((long long)n * H + 2 * yo + (w4 >> 1)) * W + 2 * xo + (w4 & 1)
-                                   : ((long long)n * H + yo) * W + xo;
+                pidx[u][w4] = POOL ? ((long long)n * H + 2 * yo + (w4 >> 1)) * W + 2 * xo + (w4 & 1) : t;
                 ry[u][w4] = bn_ld(y + pidx[u][w4] * C + grp * V);
                 if (da_full) rg[u][w4] = bn_ld(da_full + pidx[u][w4] * ld_da + grp * V);
             }
