@@ -618,12 +618,19 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(const T* __restrict_
 // small GEMMs of a 16-pixel tile on the matrix pipe instead of 8-lane dot products:
 //   logits^T[class][pixel] = W[class][k] x^T[k][pixel]        A = weight (rows = classes, padded to 16), B = 16 pixels
 //   da^T[ch][pixel]        = W^T[ch][class] d[class][pixel]   A = weight^T (four 16-channel row blocks), B = dlogits
-// The first product leaves lane (pixel = lane % 16, q = lane / 16) with classes 4q .. 4q+3 of its pixel in the four
-// accumulator registers; the second takes exactly that as its B operand when k-slot (q, j) of the MFMA stands for class
-// 4q + j (j < 4; slots 4..7 are zero on both sides) -- no lane exchange between the two.  The fp32 weight enters as
+// The first product leaves lane (pixel = lane % 16, q = lane / 16) with rows 4q .. 4q+3 of its pixel in the four
+// accumulator registers.  Weight row r holds class (r % 4) * 4 + r / 4, so register e of lane group q is class q + 4e: up
+// to 8 classes occupy registers 0 and 1 of ALL four lane groups (rows in class order would leave 6 classes in 4 + 2
+// registers of two groups, and the loss arithmetic -- which issues per register, not per active lane -- twice as long).
+// The second product takes those registers as its B operand as they stand: k-slot (q, j) of the MFMA stands for class
+// q + 4j (slots 4..7 are zero on both sides) -- no lane exchange between the two.  The fp32 weight enters as
 // hi + lo bf16 pairs (two MFMAs), dlogits likewise (d_hi W_hi + d_lo W_hi + d_hi W_lo), so the results agree with the fp32
 // arithmetic of the separate kernels to ~2^-16 before the final bf16 rounding of da.  dW / db stay on the VALU: every lane
-// fetches the (<= 8) dlogits of its pixel from the two lanes that hold them and multiplies them into its 16 channels.
+// fetches the (<= 8) dlogits of its pixel from the lanes that hold them and multiplies them into its 16 channels.
+// Both kernels are streams that were instruction-bound before they were HBM-bound: a wave's tile position (image, pixel
+// offset) is wave-uniform 32-bit state advanced by additions (no per-tile 64-bit divisions), the loop has no branches on
+// lane predicates (lanes of absent classes compute on zero rows and are dropped at the end), and da leaves as one 16-byte
+// store per lane and block pair.
 __device__ __forceinline__ uint32_t hl_pack(float a, float b) {
     typedef __attribute__((ext_vector_type(2))) float f2_t;
     typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
@@ -633,19 +640,20 @@ __device__ __forceinline__ uint32_t hl_pack(float a, float b) {
 __device__ __forceinline__ float hl_lo(float w) { return w - (float)(__bf16)w; }        // what bf16(w) leaves out
 
 struct HlFrag { u32x4 ah[2], al[2]; float bias[4]; };
-// GEMM 1 A operand: lane (row = class = lane % 16, q): k = q*8 + j  <->  input channel ks*32 + q*8 + j
+// GEMM 1 A operand: lane (row = lane % 16, q): k = q*8 + j  <->  input channel ks*32 + q*8 + j; row r <-> class (r%4)*4 + r/4
 __device__ __forceinline__ void hl_weights(HlFrag& f, const float* __restrict__ w, const float* __restrict__ bias, int Ccls, int r16, int q) {
+    const int cr = (r16 & 3) * 4 + (r16 >> 2);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = r16 < Ccls ? w[r16 * 64 + ks * 32 + q * 8 + j] : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = cr < Ccls ? w[cr * 64 + ks * 32 + q * 8 + j] : 0.f;
         f.ah[ks] = u32x4{hl_pack(v[0], v[1]), hl_pack(v[2], v[3]), hl_pack(v[4], v[5]), hl_pack(v[6], v[7])};
         f.al[ks] = u32x4{hl_pack(hl_lo(v[0]), hl_lo(v[1])), hl_pack(hl_lo(v[2]), hl_lo(v[3])),
                          hl_pack(hl_lo(v[4]), hl_lo(v[5])), hl_pack(hl_lo(v[6]), hl_lo(v[7]))};
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) f.bias[e] = 4 * q + e < Ccls ? bias[4 * q + e] : 0.f;
+    for (int e = 0; e < 4; ++e) f.bias[e] = q + 4 * e < Ccls ? bias[q + 4 * e] : 0.f;
 }
 __device__ __forceinline__ f32x4 hl_logits(const HlFrag& f, const u32x4& x0, const u32x4& x1) {
     f32x4 acc = {f.bias[0], f.bias[1], f.bias[2], f.bias[3]};
@@ -656,9 +664,55 @@ __device__ __forceinline__ f32x4 hl_logits(const HlFrag& f, const u32x4& x0, con
     return acc;
 }
 
-// Loss terms on the hardware transcendentals (v_exp_f32 / v_rcp_f32 / v_log_f32, ~1 ulp each): only 6 of the 16 lanes of a
-// row hold real classes after the swapped product, so the libm sequences of loss_terms() (expf, log1pf, a division: ~80
-// instructions per element) made these kernels VALU-bound.  |log(1 + e) - log1p(e)| <= 6e-8 absolute per element.
+// Wave-uniform position of a wave's 16-pixel tile: tile t, image n, pixel offset hw inside the image.  Tiles never straddle
+// images (H*W % 16 == 0).  All 32-bit (the launchers check N * H*W * classes < 2^31).
+struct HlWalk {
+    int t, n, hw, step_t, step_n, step_hw;
+    __device__ __forceinline__ void init(int t0, int nw, int HW) {
+        t = t0;
+        const int p0 = t0 * 16;
+        n = p0 / HW; hw = p0 - n * HW;
+        step_t = nw;
+        const int sp = nw * 16;
+        step_n = sp / HW; step_hw = sp - step_n * HW;
+    }
+    __device__ __forceinline__ void next(int HW) {
+        t += step_t; n += step_n; hw += step_hw;
+        if (hw >= HW) { hw -= HW; ++n; }
+    }
+};
+
+// One tile's operands.  Its loads are inline asm: hipcc sizes the vmcnt wait in front of a tile for the loop path with the
+// FEWEST loads behind it, so with the read-ahead under a branch every tile waited for the loads just issued; duplicating the
+// tile code per path spills.  The compiler does not know these loads are pending: hl_wait() retires them by count (vmcnt
+// retires in order, loads and stores alike) and every use of a tile comes after it.
+template <int NE> struct HlTile { u32x4 x0, x1; uint32_t t[NE]; };
+
+template <int NE, bool NT>
+__device__ __forceinline__ void hl_fetch(HlTile<NE>& d, const __bf16* xp, const uint8_t* tgt, long long toff, const int (&lc)[NE]) {
+    // (the target plane offset is wave-uniform; readfirstlane says so to the compiler, which otherwise may hand the
+    // scalar-base operand below a VGPR pair)
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)toff), hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)toff >> 32));
+    const uint8_t* tp = tgt + (long long)(((unsigned long long)hi << 32) | lo);
+    if constexpr (NT) {
+        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(d.x0) : "v"(xp) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:64 nt" : "=v"(d.x1) : "v"(xp) : "memory");
+    } else {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d.x0) : "v"(xp) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(d.x1) : "v"(xp) : "memory");
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(d.t[e]) : "v"(lc[e]), "s"(tp) : "memory");
+}
+template <int N, int NE>                          // wait until at most N vector-memory operations newer than this tile's loads are pending
+__device__ __forceinline__ void hl_wait(HlTile<NE>& d) {
+    if constexpr (NE == 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(d.x0), "+v"(d.x1), "+v"(d.t[0]) : "n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(d.x0), "+v"(d.x1), "+v"(d.t[0]), "+v"(d.t[1]) : "n"(N) : "memory");
+}
+
+// Loss terms on the hardware transcendentals (v_exp_f32 / v_rcp_f32 / v_log_f32, ~1 ulp each): the libm sequences of
+// loss_terms() (expf, log1pf, a division: ~80 instructions per element) made these kernels VALU-bound.
+// |log(1 + e) - log1p(e)| <= 6e-8 absolute per element.
 __device__ __forceinline__ void loss_terms_fast(float v, float tt, float& sb, float& si, float& sp, float& st) {
     const float e = __expf(-fabsf(v));
     const float r = __builtin_amdgcn_rcpf(1.f + e);
@@ -667,57 +721,86 @@ __device__ __forceinline__ void loss_terms_fast(float v, float tt, float& sb, fl
     si += p * tt; sp += p; st += tt;
 }
 
+#ifndef HL_SUMS_AHEAD
+#define HL_SUMS_AHEAD 1
+#endif
+#ifndef HL_SUMS_NT
+#define HL_SUMS_NT 0              // plain loads: 0.49 ms against 0.58 with nontemporal ones (the activation was written by the kernel before and is read again by the backward kernel)
+#endif
+template <int NE>                                  // accumulator registers that hold classes: (classes + 3) / 4
 __global__ __launch_bounds__(256) void head_loss_sums_mfma_kernel(const __bf16* __restrict__ a, int lda, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, const uint8_t* __restrict__ tgt,
                                                                   float* __restrict__ logits, float* __restrict__ part,
-                                                                  long long ntile, long long HW, int Ccls) {
+                                                                  int ntile, int HW, int Ccls) {
     __shared__ float red[4][8][4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r16 = lane & 15, q = lane >> 4;
     HlFrag f;
     hl_weights(f, w, bias, Ccls, r16, q);
-    float sb[4] = {0.f, 0.f, 0.f, 0.f}, si[4] = {0.f, 0.f, 0.f, 0.f}, sp[4] = {0.f, 0.f, 0.f, 0.f}, st[4] = {0.f, 0.f, 0.f, 0.f};
-    // one tile of read-ahead: the loads of tile t + nw are issued before tile t is multiplied (the kernel is a stream: at
-    // 5 waves per SIMD and no read-ahead it waited for HBM most of the time)
-    const long long nw = (long long)gridDim.x * 4;
-    u32x4 x0, x1, y0, y1;
-    uint8_t tb[4], tn[4];
-    auto fetch = [&](long long t, u32x4& u0, u32x4& u1, uint8_t (&tt)[4]) {
-        const long long p0 = t * 16, n = p0 / HW, hw = p0 - n * HW;
-        const __bf16* xr = a + (p0 + r16) * lda + q * 8;
-        u0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr));
-        u1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr + 32));
+    float sb[NE], si[NE], sp[NE], st[NE];
+    int lc[NE];                                    // target byte of (class, pixel) relative to (image, hw); absent classes read class q
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tt[e] = 4 * q + e < Ccls ? tgt[(n * Ccls + 4 * q + e) * HW + hw + r16] : (uint8_t)0;
-    };
-    long long t = (long long)blockIdx.x * 4 + wv;
-    if (t < ntile) fetch(t, x0, x1, tb);
-    while (t < ntile) {
-        const long long t2 = t + nw;
-        if (t2 < ntile) fetch(t2, y0, y1, tn);
-        const long long p0 = t * 16, n = p0 / HW, hw = p0 - n * HW;
-        const f32x4 v = hl_logits(f, x0, x1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = 4 * q + e;
-            if (c < Ccls) {
-                if (logits) logits[(n * Ccls + c) * HW + hw + r16] = v[e];
-                loss_terms_fast(v[e], tb[e] ? 1.f : 0.f, sb[e], si[e], sp[e], st[e]);
-            }
-        }
-        x0 = y0; x1 = y1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) tb[e] = tn[e];
-        t = t2;
+    for (int e = 0; e < NE; ++e) {
+        sb[e] = si[e] = sp[e] = st[e] = 0.f;
+        lc[e] = (q + 4 * e < Ccls ? q + 4 * e : q < Ccls ? q : 0) * HW + r16;
     }
-    // lanes with equal q hold the same four classes: sum over the 16 pixels lanes, then over the four waves
+    const int nw = gridDim.x * 4;
+    HlWalk cur, ahead;                                // the tile being multiplied; the next tile to ask for
+    cur.init(blockIdx.x * 4 + wv, nw, HW);
+    ahead = cur;
+    const __bf16* xc = a + ((long long)cur.t * 16 + r16) * lda + q * 8;      // this lane's row of `cur` ...
+    const __bf16* xa = xc;                                                   // ... and of `ahead`
+    const long long xstep = (long long)nw * 16 * lda;
+    const int CHW = Ccls * HW;
+    // D tiles of read-ahead on a ring of D + 1 register sets, no copies.  Past the last tile the fetch asks for the current
+    // tile again: every tile then has the same number of loads behind it.
+    constexpr int D = HL_SUMS_AHEAD;
+    HlTile<NE> ring[D + 1];
+    auto fetch = [&](HlTile<NE>& d) {
+        const bool more = ahead.t < ntile;
+        const HlWalk& k = more ? ahead : cur;
+        hl_fetch<NE, HL_SUMS_NT != 0>(d, more ? xa : xc, tgt, (long long)k.n * CHW + k.hw, lc);
+        xa += xstep; ahead.next(HW);                  // (past the end neither is dereferenced)
+    };
+    auto tile = [&](const HlTile<NE>& c) {
+        const f32x4 v = hl_logits(f, c.x0, c.x1);
+        if (logits) {                                                  // (uniform)
+            float* lp = logits + ((long long)cur.n * CHW + cur.hw);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < NE; ++e)
+                if (q + 4 * e < Ccls) lp[lc[e]] = v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) loss_terms_fast(v[e], c.t[e] ? 1.f : 0.f, sb[e], si[e], sp[e], st[e]);
+    };
+    // behind a tile's loads when it is waited for: D fetches of 2 + NE loads (and logits stores, if any: the wait is then
+    // stronger than needed)
+    if (cur.t < ntile) {
+        sfor<0, D>([&](auto ic) { fetch(ring[decltype(ic)::value]); });
+        bool done = false;
+        while (!done) {
+            sfor<0, D + 1>([&](auto sc) {
+                constexpr int s_ = decltype(sc)::value;
+                if (!done) {
+                    fetch(ring[(s_ + D) % (D + 1)]);
+                    hl_wait<D * (2 + NE)>(ring[s_]);
+                    tile(ring[s_]);
+                    cur.next(HW); xc += xstep;
+                    done = cur.t >= ntile;
+                }
+            });
+        }
+        // the repeated fetches still target these registers: keep them out of other use until they have landed
+        sfor<0, D + 1>([&](auto ic) { hl_wait<0>(ring[decltype(ic)::value]); });
+    }
+    // lanes with equal q hold the same classes: sum over the 16 pixel lanes, then over the four waves
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
         float vals[4] = {sb[e], si[e], sp[e], st[e]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float x = vals[k];
             x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
-            if (r16 == 0 && q < 2) red[wv][4 * q + e][k] = x;
+            if (r16 == 0) red[wv][q + 4 * e][k] = x;
         }
     }
     __syncthreads();
@@ -727,14 +810,18 @@ __global__ __launch_bounds__(256) void head_loss_sums_mfma_kernel(const __bf16* 
     }
 }
 
-template <int NC>                                  // classes the dW accumulators are sized for (6 or 8)
+#ifndef HL_BWD_AHEAD
+#define HL_BWD_AHEAD 1            // 2 measured the same (0.96 vs 0.95 ms at batch 64 @512^2): the kernel is not waiting for HBM latency
+#endif
+template <int NC, int D>                           // classes the dW accumulators are sized for (4, 6 or 8); tiles of read-ahead
 __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16* __restrict__ a, int lda, const float* __restrict__ w,
                                                                     const float* __restrict__ bias, const uint8_t* __restrict__ tgt,
                                                                     const double* __restrict__ sums, float* __restrict__ loss,
                                                                     __bf16* __restrict__ da, int ldda, float* __restrict__ part,
-                                                                    float gscale, long long ntile, long long HW, int N, int Ccls) {
+                                                                    float gscale, int ntile, int HW, int N, int Ccls) {
+    constexpr int NE = (NC + 3) / 4;
     __shared__ float red[4][NC * 65];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r16 = lane & 15, q = lane >> 4;
     const long long total = (long long)N * Ccls * HW;
     if (blockIdx.x == 0 && threadIdx.x == 0 && loss) {
         double bce = 0.0, dice = 0.0;
@@ -746,95 +833,126 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
     }
     HlFrag f;
     hl_weights(f, w, bias, Ccls, r16, q);
-    // GEMM 2 A operand, row block mb: lane (row = channel mb*16 + lane % 16, q): k-slot j < 4 <-> class 4q + j, slots 4..7 zero
+    // GEMM 2 A operand, row block mb: lane (row = lane % 16, q): k-slot j < 4 <-> class q + 4j, slots 4..7 zero.  Row i of
+    // block mb is channel 32 (mb / 2) + 8 (i / 4) + 4 (mb % 2) + i % 4: the accumulators of a lane over a block pair are
+    // eight consecutive channels.
     u32x4 w2h[4], w2l[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
+        const int ch = 32 * (mb >> 1) + 8 * (r16 >> 2) + 4 * (mb & 1) + (r16 & 3);
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = 4 * q + j < Ccls ? w[(4 * q + j) * 64 + mb * 16 + r16] : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = q + 4 * j < Ccls ? w[(q + 4 * j) * 64 + ch] : 0.f;
         w2h[mb] = u32x4{hl_pack(v[0], v[1]), hl_pack(v[2], v[3]), 0u, 0u};
         w2l[mb] = u32x4{hl_pack(hl_lo(v[0]), hl_lo(v[1])), hl_pack(hl_lo(v[2]), hl_lo(v[3])), 0u, 0u};
     }
-    float cf0[4], cf1[4];                             // per class of this lane: 1/(S+1), (2I+1)/(S+1)
+    float cf0[NE], cf1[NE];                           // per class of this lane: 1/(S+1), (2I+1)/(S+1)
+    bool have[NE];
+    int lc[NE];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int c = 4 * q + e;
-        const double I = c < Ccls ? sums[c * 4 + 1] : 0.0, S = c < Ccls ? sums[c * 4 + 2] + sums[c * 4 + 3] : 0.0;
+    for (int e = 0; e < NE; ++e) {
+        const int c = q + 4 * e;
+        have[e] = c < Ccls;
+        const double I = have[e] ? sums[c * 4 + 1] : 0.0, S = have[e] ? sums[c * 4 + 2] + sums[c * 4 + 3] : 0.0;
         cf0[e] = (float)(1.0 / (S + 1.0));
         cf1[e] = (float)((2.0 * I + 1.0) / (S + 1.0));
+        lc[e] = (have[e] ? c : q < Ccls ? q : 0) * HW + r16;
     }
-    const float itot = 1.f / (float)total, ic = 1.f / (float)Ccls;
-    float gw[NC][16], gb[4] = {0.f, 0.f, 0.f, 0.f};
+    const float itot = gscale / (float)total, ic = gscale / (float)Ccls;
+    float gw[NC][16], gb[NE];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int j = 0; j < 16; ++j) gw[c][j] = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) gb[e] = 0.f;
 
-    const long long nw = (long long)gridDim.x * 4;
-    u32x4 x0, x1, y0, y1;
-    uint8_t tb[4], tn[4];
-    auto fetch = [&](long long t, u32x4& u0, u32x4& u1, uint8_t (&tt)[4]) {
-        const long long p0 = t * 16, n = p0 / HW, hw = p0 - n * HW;
-        const __bf16* xr = a + (p0 + r16) * lda + q * 8;
-        u0 = *reinterpret_cast<const u32x4*>(xr);
-        u1 = *reinterpret_cast<const u32x4*>(xr + 32);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) tt[e] = 4 * q + e < Ccls ? tgt[(n * Ccls + 4 * q + e) * HW + hw + r16] : (uint8_t)0;
+    const int nw = gridDim.x * 4;
+    HlWalk cur, ahead;                                // the tile being multiplied; the next tile to ask for
+    cur.init(blockIdx.x * 4 + wv, nw, HW);
+    ahead = cur;
+    const __bf16* xc = a + ((long long)cur.t * 16 + r16) * lda + q * 8;      // this lane's row of `cur` ...
+    const __bf16* xa = xc;                                                   // ... and of `ahead`
+    __bf16* dp = da + ((long long)cur.t * 16 + r16) * ldda + q * 8;
+    const long long xstep = (long long)nw * 16 * lda, dstep = (long long)nw * 16 * ldda;
+    const int CHW = Ccls * HW;
+    // D tiles of read-ahead (two waves per SIMD do not hide HBM latency) on a ring of D + 1 register sets, no copies.  Past
+    // the last tile the fetch asks for the current tile again: every tile then has the same number of loads behind it.
+    HlTile<NE> ring[D + 1];
+    auto fetch = [&](HlTile<NE>& d) {
+        const bool more = ahead.t < ntile;
+        const HlWalk& k = more ? ahead : cur;
+        hl_fetch<NE, false>(d, more ? xa : xc, tgt, (long long)k.n * CHW + k.hw, lc);
+        xa += xstep; ahead.next(HW);                  // (past the end neither is dereferenced)
     };
-    long long t = (long long)blockIdx.x * 4 + wv;
-    if (t < ntile) fetch(t, x0, x1, tb);
-    while (t < ntile) {
-        const long long t2 = t + nw;
-        if (t2 < ntile) fetch(t2, y0, y1, tn);          // one tile of read-ahead (two waves per SIMD do not hide HBM latency)
-        const long long p0 = t * 16;
-        const f32x4 v = hl_logits(f, x0, x1);
-        float d[4];
+    auto tile = [&](const HlTile<NE>& c) {
+        const f32x4 v = hl_logits(f, c.x0, c.x1);
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = 4 * q + e;
-            d[e] = 0.f;
-            if (c < Ccls) {
-                const float tt = tb[e] ? 1.f : 0.f;
-                const float ex = __expf(-fabsf(v[e]));
-                const float r = __builtin_amdgcn_rcpf(1.f + ex);
-                const float pr = v[e] >= 0.f ? r : ex * r;
-                const float ddice = (2.f * tt - cf1[e]) * cf0[e];
-                d[e] = ((pr - tt) * itot - ddice * pr * (1.f - pr) * ic) * gscale;
-                gb[e] += d[e];
-            }
+        for (int e = 0; e < NE; ++e) {
+            const float tt = c.t[e] ? 1.f : 0.f;
+            const float ex = __expf(-fabsf(v[e]));
+            const float r = __builtin_amdgcn_rcpf(1.f + ex);
+            const float pr = v[e] >= 0.f ? r : ex * r;
+            const float ddice = (2.f * tt - cf1[e]) * cf0[e];
+            const float de = (pr - tt) * itot - ddice * pr * (1.f - pr) * ic;
+            d[e] = have[e] ? de : 0.f;
+            gb[e] += d[e];
         }
         // da = W^T d on the matrix pipe
         const u32x4 bh = {hl_pack(d[0], d[1]), hl_pack(d[2], d[3]), 0u, 0u};
         const u32x4 bl = {hl_pack(hl_lo(d[0]), hl_lo(d[1])), hl_pack(hl_lo(d[2]), hl_lo(d[3])), 0u, 0u};
-        __bf16* dr = da + (p0 + r16) * ldda + 4 * q;
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2h[mb]), __builtin_bit_cast(bf16x8, bh), o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2h[mb]), __builtin_bit_cast(bf16x8, bl), o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2l[mb]), __builtin_bit_cast(bf16x8, bh), o, 0, 0, 0);
-            *reinterpret_cast<u32x2*>(dr + mb * 16) = u32x2{hl_pack(o[0], o[1]), hl_pack(o[2], o[3])};
+        for (int mp = 0; mp < 2; ++mp) {
+            f32x4 o[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int mb = 2 * mp + h;
+                o[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                o[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2h[mb]), __builtin_bit_cast(bf16x8, bh), o[h], 0, 0, 0);
+                o[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2h[mb]), __builtin_bit_cast(bf16x8, bl), o[h], 0, 0, 0);
+                o[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2l[mb]), __builtin_bit_cast(bf16x8, bh), o[h], 0, 0, 0);
+            }
+            *reinterpret_cast<u32x4*>(dp + mp * 32) = u32x4{hl_pack(o[0][0], o[0][1]), hl_pack(o[0][2], o[0][3]),
+                                                            hl_pack(o[1][0], o[1][1]), hl_pack(o[1][2], o[1][3])};
         }
-        // dW: the dlogits of this lane's pixel for every class (lanes (pixel, 0) and (pixel, 1) hold them) x its 16 channels
+        dp += dstep;
+        // dW: the dlogits of this lane's pixel for every class (lane (pixel, c % 4) holds class c in register c / 4) x its 16 channels
         float xf[16];
         {
-            const bf16x8 b0 = __builtin_bit_cast(bf16x8, x0), b1 = __builtin_bit_cast(bf16x8, x1);
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, c.x0), b1 = __builtin_bit_cast(bf16x8, c.x1);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { xf[j] = (float)b0[j]; xf[8 + j] = (float)b1[j]; }
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             if (c < Ccls) {                                  // (uniform)
-                const float dc = __shfl(d[c & 3], r16 + 16 * (c >> 2));
+                const float dc = __shfl(d[c >> 2], r16 + 16 * (c & 3));
 #pragma unroll
                 for (int j = 0; j < 16; ++j) gw[c][j] = __builtin_fmaf(dc, xf[j], gw[c][j]);
             }
         }
-        x0 = y0; x1 = y1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) tb[e] = tn[e];
-        t = t2;
+    };
+    // Behind a tile's loads when it is waited for: D fetches of 2 + NE loads and the two da stores of each of the D tiles before
+    // it.  The first D tiles have fewer stores behind them: they are waited for outright.
+    if (cur.t < ntile) {
+        sfor<0, D>([&](auto ic) { fetch(ring[decltype(ic)::value]); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bool done = false;
+        while (!done) {
+            sfor<0, D + 1>([&](auto sc) {
+                constexpr int s_ = decltype(sc)::value;
+                if (!done) {
+                    fetch(ring[(s_ + D) % (D + 1)]);
+                    hl_wait<D * (4 + NE)>(ring[s_]);
+                    tile(ring[s_]);
+                    cur.next(HW); xc += xstep;
+                    done = cur.t >= ntile;
+                }
+            });
+        }
+        // the repeated fetches still target these registers: keep them out of other use until they have landed
+        sfor<0, D + 1>([&](auto ic) { hl_wait<0>(ring[decltype(ic)::value]); });
     }
     // reduce over the 16 pixel lanes, then over the four waves; lane (0, q) owns channels q*8 .. +7 and 32 + q*8 .. +7
 #pragma unroll
@@ -846,10 +964,10 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
             if (r16 == 0) red[wv][c * 65 + (j >> 3) * 32 + q * 8 + (j & 7)] = x;
         }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NE; ++e) {
         float x = gb[e];
         x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
-        if (r16 == 0 && 4 * q + e < NC) red[wv][(4 * q + e) * 65 + 64] = x;
+        if (r16 == 0 && q + 4 * e < NC) red[wv][(q + 4 * e) * 65 + 64] = x;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < Ccls * 65; i += 256)
@@ -946,7 +1064,9 @@ extern "C" int fea_head_loss_sums(const void* a, int lda, const float* w, const 
     const long long npix = (long long)N * H * W, HW = (long long)H * W;
     const int nblk = head_blocks(npix);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == FEA_BF16 && HW % 16 == 0) hipLaunchKernelGGL(head_loss_sums_mfma_kernel, dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, logits, part, npix / 16, HW, Ccls);
+    const bool mfma = dtype == FEA_BF16 && HW % 16 == 0 && npix * Ccls < (1ll << 31);       // 32-bit tile positions and target offsets
+    if (mfma && Ccls <= 4) hipLaunchKernelGGL(head_loss_sums_mfma_kernel<1>, dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, logits, part, (int)(npix / 16), (int)HW, Ccls);
+    else if (mfma) hipLaunchKernelGGL(head_loss_sums_mfma_kernel<2>, dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, logits, part, (int)(npix / 16), (int)HW, Ccls);
     else if (dtype == FEA_BF16) hipLaunchKernelGGL((head_loss_sums_kernel<__bf16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, logits, part, npix / 4, HW, Ccls);
     else if (dtype == FEA_F32) hipLaunchKernelGGL((head_loss_sums_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)a, lda, w, bias, target, logits, part, npix / 4, HW, Ccls);
     else { fea_set_error("%s: bad dtype", who); return FEA_E_BADARG; }
@@ -970,8 +1090,10 @@ extern "C" int fea_head_loss_bwd(const void* a, int lda, const float* w, const f
     long long ppb = (npix + nblk - 1) / nblk;
     ppb = (ppb + 63) / 64 * 64;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == FEA_BF16 && HW % 16 == 0 && Ccls <= 6) hipLaunchKernelGGL(head_loss_bwd_mfma_kernel<6>, dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, npix / 16, HW, N, Ccls);
-    else if (dtype == FEA_BF16 && HW % 16 == 0) hipLaunchKernelGGL(head_loss_bwd_mfma_kernel<8>, dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, npix / 16, HW, N, Ccls);
+    const bool mfma = dtype == FEA_BF16 && HW % 16 == 0 && npix * Ccls < (1ll << 31);       // as in fea_head_loss_sums
+    if (mfma && Ccls <= 4) hipLaunchKernelGGL((head_loss_bwd_mfma_kernel<4, HL_BWD_AHEAD>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, (int)(npix / 16), (int)HW, N, Ccls);
+    else if (mfma && Ccls <= 6) hipLaunchKernelGGL((head_loss_bwd_mfma_kernel<6, HL_BWD_AHEAD>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, (int)(npix / 16), (int)HW, N, Ccls);
+    else if (mfma) hipLaunchKernelGGL((head_loss_bwd_mfma_kernel<8, 1>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, (int)(npix / 16), (int)HW, N, Ccls);
     else if (dtype == FEA_BF16) hipLaunchKernelGGL((head_loss_bwd_kernel<__bf16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, npix, HW, N, Ccls, ppb);
     else if (dtype == FEA_F32) hipLaunchKernelGGL((head_loss_bwd_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)a, lda, w, bias, target, sums, loss, (float*)da, ldda, part, gscale, npix, HW, N, Ccls, ppb);
     else { fea_set_error("%s: bad dtype", who); return FEA_E_BADARG; }
