@@ -87,6 +87,9 @@ struct TapSched {
     static constexpr int N(int s) { return issued_before(s) - (need(s) + 1); }
 };
 
+#ifndef IG_GATHER_REGS
+#define IG_GATHER_REGS 1
+#endif
 template <typename T, int MODE, int BN, int EPI, int TWS>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     constexpr int CK = Elem<T>::CK, EPC = Elem<T>::EPC;
@@ -99,7 +102,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     // (fragment-ordered pack, 1 KB contiguous per wave-instruction): no weight tile
     // in LDS and NO per-tap barrier; the A halo tile is the only LDS resident.
     constexpr bool DB = MODE == 0 && sizeof(T) == 2 && BN == 64;   // (BN = 128: doubling the L2 weight traffic costs more than the barrier)
-    constexpr int NWBUF = DB ? 0 : (MODE == 0 ? 2 : 1);
+    constexpr bool GR = MODE == 2 && IG_GATHER_REGS;   // (MODE 1 measured slower with it: 128->64 @256^2 0.80 -> 0.96 ms)
+    constexpr int NWBUF = DB ? 0 : ((MODE == 0 || GR) ? 2 : 1);
     constexpr int W_BYTES = BN * 128;
     constexpr int W_PASSES = BN / 32;
     constexpr int EPI_STRIDE = BN * 2 + 16;      // bf16 staging row, padded
@@ -446,12 +450,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
         const int KS = (9 * C + 31) >> 5;                  // 1 or 2 k-steps of 32
         float* hal = reinterpret_cast<float*>(smem);
         const float* __restrict__ xin = (const float*)g.x + (long long)n_img * g.x_img_stride;
-        for (int e = tid; e < C * HALO; e += 256) {
+        // all of a thread's halo loads are issued before the first is stored (a rolled loop waits for each load in turn:
+        // four exposed HBM latencies per workgroup of a kernel that is otherwise one output store)
+        constexpr int HIT = (7 * HALO + 255) / 256;           // 9 C <= 64  =>  C <= 7
+        float hv[HIT];
+#pragma unroll
+        for (int i = 0; i < HIT; ++i) {
+            const int e = tid + i * 256;
             const int c = e / HALO, rr = e - c * HALO;
             const int hy = rr / HW2, hx = rr - hy * HW2;
             const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            hal[e] = ok ? xin[((long long)c * H + gy) * W + gx] : 0.f;
+            const bool ok = e < C * HALO && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            hv[i] = ok ? xin[((long long)c * H + gy) * W + gx] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < HIT; ++i) {
+            const int e = tid + i * 256;
+            if (e < C * HALO) hal[e] = hv[i];
         }
         u32x4 Bf[2][4];
         int koff[2][8];
@@ -465,9 +480,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = ks * 32 + q16 * 8 + j;
-                const int tap = k / C, c = k - tap * C;
+                const int tap = C == 3 ? k / 3 : k / C, c = k - tap * C;    // (RGB: constant divisor; 16 runtime divisions otherwise)
                 const int dy = tap / 3, dx = tap - dy * 3;
-                koff[ks][j] = k < 9 * C ? c * HALO + dy * HW2 + dx : -1;
+                // k >= 9 C: the packed weight is zero (pack_conv3x3_first_kernel), any finite operand will do: no branch
+                koff[ks][j] = k < 9 * C ? c * HALO + dy * HW2 + dx : 0;
             }
         }
         __syncthreads();
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
                 if (ks < KS) {
                     bf16x8 af;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) af[j] = (__bf16)(koff[ks][j] >= 0 ? hal[pb + koff[ks][j]] : 0.f);
+                    for (int j = 0; j < 8; ++j) af[j] = (__bf16)hal[pb + koff[ks][j]];
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
                         acc16[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, Bf[ks][n]), acc16[m][n], 0, 0, 0);
@@ -537,6 +553,33 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
         const int ntaps = MODE == 2 ? 4 : 1;
         const int nk = ntaps * nchunks;
         // kc = tap * nchunks + chunk
+        if constexpr (GR) {
+        // The next k-chunk is on its way while this one is multiplied: its pixels travel global -> registers (written to LDS
+        // after the barrier, in the layout the LDS-DMA path writes: wave-instruction j fills 1 KB linearly, swizzle on the
+        // source), its weights by LDS-DMA into the other of two weight tiles.  With both staged by DMA between two barriers
+        // the chunk's whole HBM latency was exposed in every chunk (only the CU's other workgroup covered it).
+        u32x4 ra[A_PASSES];
+        auto load_A = [&](int kc) {
+            const int tap = MODE == 2 ? kc / nchunks : 0;
+            const int ch = kc - tap * nchunks;
+            const int tap_off = MODE == 2 ? ((tap >> 1) * (2 * W) + (tap & 1)) * g.ldx : 0;
+#pragma unroll
+            for (int i = 0; i < A_PASSES; ++i) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                ra[i] = ((a_valid >> i) & 1) ? *reinterpret_cast<const u32x4*>(xg + a_off[i] + tap_off + ch * CK) : z;
+            }
+        };
+        load_A(0);
+        stage_W(0, 0);
+        for (int kc = 0; kc < nk; ++kc) {
+            __syncthreads();                       // previous k-chunk consumed; this chunk's weights have landed
+#pragma unroll
+            for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<u32x4*>(ldsA + (i * 4 + wave) * 1024 + lane * 16) = ra[i];
+            __syncthreads();
+            if (kc + 1 < nk) { load_A(kc + 1); stage_W(kc + 1, (kc + 1) & 1); }
+            compute(0, kc & 1);
+        }
+        } else {
         for (int kc = 0; kc < nk; ++kc) {
             const int tap = MODE == 2 ? kc / nchunks : 0;
             const int ch = kc - tap * nchunks;
@@ -546,6 +589,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
             stage_A(ch, tap_off);
             __syncthreads();
             compute(0, 0);
+        }
         }
     }
     __syncthreads();                               // LDS is reused by the epilogue
