@@ -29,6 +29,8 @@ SIGNATURES = {
     "fea_pack_conv3x3": (I, [P, P, I, I, I, I, P]),
     "fea_pack_conv3x3_im2col": (I, [P, P, I, I, I, I, P]),
     "fea_pack_upconv2x2": (I, [P, P, I, I, I, I, P]),
+    "fea_pack_job_blocks": (I, [I, I, I, I]),
+    "fea_pack_batch": (I, [P, I, I, I, P]),
     "fea_pack_conv3x3_first": (I, [P, P, I, I, I, P]),
     "fea_conv3x3_first": (I, [P, P, P, P, I, P, I, I, I, I, I, I, P]),
     "fea_first_wgrad_ws_bytes": (Z, [I, I, I, I]),

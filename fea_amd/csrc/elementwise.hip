@@ -94,33 +94,50 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
 //         out[kc][row/16][kk/32][lane = ((kk/8)&3)*16 + row%16][kk%8]
 //         = the 16x16x32 MFMA B fragments in the order the conv kernel's waves load them
 //         (one contiguous KB per wave-instruction, global -> VGPR)
+// One thread makes the nine taps of one (row, k) pair: it reads the nine fp32 values of a 3x3 filter (36 contiguous bytes;
+// one element per thread read them at a stride of nine floats, each tap from a far-away block: nine sweeps over the
+// tensor) and stores one element into each of the nine tap images.  i < rows * kch.
 template <typename T>
-__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int dgrad, int force_frag) {
+__device__ __forceinline__ void pack_conv3x3_elem(long long i, const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int dgrad, int force_frag) {
     constexpr int CK = Elem<T>::CK;
     const int rows = dgrad ? Ci : Co;          // GEMM N
     const int kch = dgrad ? Co : Ci;           // GEMM K channels
-    const long long total = (long long)9 * rows * kch;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int row, kk, kc;
+    if (i >= (long long)rows * kch) return;
+    // 32-bit index arithmetic (the entry points check 9 * Co * Ci < 2^31)
+    const unsigned iu = (unsigned)i;
+    int row, kk, chunk;
+    unsigned o0, ostride;                      // element of tap 0, distance between taps
     if (force_frag || fea_conv3x3_frag_pack(rows, sizeof(T))) {
-        const int j = (int)(i & 7), ln = (int)((i >> 3) & 63), ks = (int)((i >> 9) & 1);
-        const long long blk = i >> 10;
-        const int nt16 = rows >> 4;
-        kc = (int)(blk / nt16);
-        row = (int)(blk % nt16) * 16 + (ln & 15);
+        // out index = ((chunk * 9 + tap) * nt16 + nt) << 10 | ks << 9 | lane << 3 | j
+        const int j = (int)(iu & 7), ln = (int)((iu >> 3) & 63), ks = (int)((iu >> 9) & 1);
+        const unsigned blk = iu >> 10;
+        const unsigned nt16 = (unsigned)rows >> 4;
+        chunk = (int)(blk / nt16);
+        const unsigned nt = blk - (unsigned)chunk * nt16;
+        row = (int)nt * 16 + (ln & 15);
         kk = ks * 32 + (ln >> 4) * 8 + j;
+        o0 = (((unsigned)chunk * 9 * nt16 + nt) << 10) | (iu & 1023);
+        ostride = nt16 << 10;
     } else {
-        kk = (int)(i % CK);
-        row = (int)((i / CK) % rows);
-        kc = (int)(i / ((long long)CK * rows));
+        // out index = ((chunk * 9 + tap) * rows + row) * CK + kk
+        kk = (int)(iu % CK);
+        const unsigned r = iu / CK;
+        chunk = (int)(r / (unsigned)rows);
+        row = (int)(r - (unsigned)chunk * (unsigned)rows);
+        o0 = ((unsigned)chunk * 9 * (unsigned)rows + (unsigned)row) * CK + (unsigned)kk;
+        ostride = (unsigned)rows * CK;
     }
-    const int chunk = kc / 9, tap = kc - chunk * 9;
     const int kg = chunk * CK + kk;
-    float v;
-    if (!dgrad) v = w[((long long)row * Ci + kg) * 9 + tap];
-    else        v = w[((long long)kg * Ci + row) * 9 + (8 - tap)];
-    out[i] = from_f32<T>(v);
+    const float* src = dgrad ? w + ((long long)kg * Ci + row) * 9 : w + ((long long)row * Ci + kg) * 9;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = src[t];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) out[o0 + (unsigned)t * ostride] = from_f32<T>(v[dgrad ? 8 - t : t]);
+}
+template <typename T>
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int dgrad, int force_frag) {
+    pack_conv3x3_elem<T>((long long)blockIdx.x * blockDim.x + threadIdx.x, w, out, Co, Ci, dgrad, force_frag);
 }
 template <typename T>
 __global__ void pack_conv3x3_im2col_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int C, int Kpad) {
@@ -138,9 +155,8 @@ __global__ void pack_conv3x3_im2col_kernel(const float* __restrict__ w, T* __res
     out[i] = from_f32<T>(v);
 }
 // first layer (fea_conv3x3_first): out[ks][co/16][lane = q*16 + co%16][j], k = ks*32 + q*8 + j = tap*C + c
-__global__ void pack_conv3x3_first_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Co, int C, int KS) {
+__device__ __forceinline__ void pack_conv3x3_first_elem(long long i, const float* __restrict__ w, __bf16* __restrict__ out, int Co, int C, int KS) {
     const long long total = (long long)KS * Co * 32;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int j = (int)(i & 7), ln = (int)((i >> 3) & 63);
     const long long blk = i >> 9;
@@ -151,28 +167,59 @@ __global__ void pack_conv3x3_first_kernel(const float* __restrict__ w, __bf16* _
     if (k < 9 * C) { const int tap = k / C, c = k - tap * C; v = w[((long long)co * C + c) * 9 + tap]; }
     out[i] = (__bf16)v;
 }
+__global__ void pack_conv3x3_first_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Co, int C, int KS) {
+    pack_conv3x3_first_elem((long long)blockIdx.x * blockDim.x + threadIdx.x, w, out, Co, C, KS);
+}
 
 template <typename T>
-__global__ void pack_upconv_kernel(const float* __restrict__ w, T* __restrict__ out, int Ci, int Co, int bwd) {
+__device__ __forceinline__ void pack_upconv_elem(long long i, const float* __restrict__ w, T* __restrict__ out, int Ci, int Co, int bwd) {
     constexpr int CK = Elem<T>::CK;
     const long long total = (long long)4 * Ci * Co;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int j = (int)(i % CK);
+    const unsigned iu = (unsigned)i;             // (4 * Ci * Co < 2^31, checked by the entry points)
+    const int j = (int)(iu % CK);
+    const unsigned r = iu / CK;
     float v;
     if (!bwd) {       // out[chunk][ab*Co+co][j] = w[chunk*CK+j][co][ab]
-        const int row = (int)((i / CK) % (4 * Co));
-        const int chunk = (int)(i / ((long long)CK * 4 * Co));
+        const int chunk = (int)(r / (unsigned)(4 * Co));
+        const int row = (int)(r - (unsigned)chunk * (unsigned)(4 * Co));
         const int ab = row / Co, co = row - ab * Co;
         v = w[(((long long)(chunk * CK + j)) * Co + co) * 4 + ab];
     } else {          // out[ab*(Co/CK)+chunk][ci][j] = w[ci][chunk*CK+j][ab]
-        const int ci = (int)((i / CK) % Ci);
-        const int kc = (int)(i / ((long long)CK * Ci));
+        const int kc = (int)(r / (unsigned)Ci);
+        const int ci = (int)(r - (unsigned)kc * (unsigned)Ci);
         const int nch = Co / CK;
         const int ab = kc / nch, chunk = kc - ab * nch;
         v = w[((long long)ci * Co + chunk * CK + j) * 4 + ab];
     }
     out[i] = from_f32<T>(v);
+}
+template <typename T>
+__global__ void pack_upconv_kernel(const float* __restrict__ w, T* __restrict__ out, int Ci, int Co, int bwd) {
+    pack_upconv_elem<T>((long long)blockIdx.x * blockDim.x + threadIdx.x, w, out, Ci, Co, bwd);
+}
+
+// Every weight pack of a training step in ONE launch (fea_pack_batch): a step re-packs ~43 tensors, most of them far
+// smaller than a launch is long.  Block b serves the job with the largest first_block <= b.
+struct PackJob { const float* src; void* dst; int kind, a, b, c, first_block, reserved; };     // == FeaPackJob (fea_unet.h)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    __shared__ int which;
+    if (threadIdx.x < 64) {
+        const bool le = (int)threadIdx.x < njobs && jobs[threadIdx.x].first_block <= (int)blockIdx.x;
+        const unsigned long long m = __ballot(le);
+        if (threadIdx.x == 0) which = __popcll(m) - 1;
+    }
+    __syncthreads();
+    const PackJob j = jobs[which];
+    const long long i = (long long)(blockIdx.x - j.first_block) * 256 + threadIdx.x;
+    switch (j.kind) {
+        case 0: pack_conv3x3_elem<T>(i, j.src, (T*)j.dst, j.a, j.b, j.c, 0); break;
+        case 1: if constexpr (sizeof(T) == 2) pack_conv3x3_elem<T>(i, j.src, (T*)j.dst, j.a, j.b, j.c, 1); break;
+        case 2: pack_upconv_elem<T>(i, j.src, (T*)j.dst, j.a, j.b, j.c); break;
+        case 3: if constexpr (sizeof(T) == 2) pack_conv3x3_first_elem(i, j.src, (__bf16*)j.dst, j.a, j.b, (9 * j.b + 31) / 32); break;
+        default: break;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -193,29 +240,48 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 // [b*rpb, (b+1)*rpb) with coalesced row reads (double accumulation) and stores the result
 // into its own first row, so the finalize kernels read `nb` rows at stride rpb.
 __global__ __launch_bounds__(256) void fold_rows_kernel(float* __restrict__ part, int nrows, int ldf, int rpb) {
-    __shared__ double red[256];
-    const int L = ldf < 256 ? ldf : 256, slots = 256 / L;
+    // 16 bytes per lane, four rows in flight per thread (one dword per lane and one row at a time took 24 us per call on
+    // the 33 MB tables of the 512x512 layers: twelve calls per step)
+    __shared__ double red[256][4];
+    const int ld4 = ldf >> 2;                    // host guarantees ldf % 4 == 0
+    const int L = ld4 < 256 ? ld4 : 256, slots = 256 / L;
     const int cl = threadIdx.x % L, slot = threadIdx.x / L;
     const int r0 = blockIdx.x * rpb, r1 = min(r0 + rpb, nrows);
-    for (int c0 = 0; c0 < ldf; c0 += 256) {
+    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(part);
+    for (int c0 = 0; c0 < ld4; c0 += 256) {
         const int col = c0 + cl;
-        double a = 0.0;
-        if (slot < slots && col < ldf)
-            for (int r = r0 + slot; r < r1; r += slots) a += (double)part[(long long)r * ldf + col];
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        if (slot < slots && col < ld4) {
+            int r = r0 + slot;
+            for (; r + 3 * slots < r1; r += 4 * slots) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = p4[(long long)(r + u * slots) * ld4 + col];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[0] += (double)v[u].x; a[1] += (double)v[u].y; a[2] += (double)v[u].z; a[3] += (double)v[u].w; }
+            }
+            for (; r < r1; r += slots) {
+                const float4 v = p4[(long long)r * ld4 + col];
+                a[0] += (double)v.x; a[1] += (double)v.y; a[2] += (double)v.z; a[3] += (double)v.w;
+            }
+        }
         __syncthreads();                          // every read of row r0 is done before it is overwritten
-        red[threadIdx.x] = a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = a[j];
         __syncthreads();
-        if (slot == 0 && col < ldf) {
-            double t = 0.0;
-            for (int sl = 0; sl < slots; ++sl) t += red[sl * L + cl];
-            part[(long long)r0 * ldf + col] = (float)t;
+        if (slot == 0 && col < ld4) {
+            double t[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int sl = 0; sl < slots; ++sl)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] += red[sl * L + cl][j];
+            reinterpret_cast<float4*>(part)[(long long)r0 * ld4 + col] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
         }
     }
 }
 static void fold_rows(float* part, int& nrows, int& rstride, int ldf, hipStream_t s) {
     rstride = 1;
-    if (nrows < 4096 || ldf % 2 || (ldf > 256 && ldf % 256)) return;
-    const int nb = 256, rpb = (nrows + nb - 1) / nb;
+    if (nrows < 4096 || ldf % 4 || (ldf > 1024 && ldf % 1024) || ((uintptr_t)part & 15)) return;
+    const int nb = 1024, rpb = (nrows + nb - 1) / nb;
     const int nfold = (nrows + rpb - 1) / rpb;
     hipLaunchKernelGGL(fold_rows_kernel, dim3(nfold), dim3(256), 0, s, part, nrows, ldf, rpb);
     nrows = nfold; rstride = rpb;
@@ -586,8 +652,9 @@ extern "C" int fea_pack_conv3x3(const float* w, void* out, int Co, int Ci, int d
     FEA_CHECK(w && out && Co > 0 && Ci > 0, FEA_E_BADARG, "fea_pack_conv3x3: bad args");
     FEA_CHECK((dgrad ? Co : Ci) % CK == 0, FEA_E_UNSUPPORTED_SHAPE, "fea_pack_conv3x3: K channels not a multiple of %d", CK);
     const long long total = (long long)9 * Co * Ci;
+    FEA_CHECK(total < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "fea_pack_conv3x3: %lld elements", total);
     DT_SWITCH(dtype, "fea_pack_conv3x3",
-              hipLaunchKernelGGL((pack_conv3x3_kernel<T>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, w, (T*)out, Co, Ci, dgrad, 0));
+              hipLaunchKernelGGL((pack_conv3x3_kernel<T>), GRID1D(total / 9, 256), dim3(256), 0, (hipStream_t)stream, w, (T*)out, Co, Ci, dgrad, 0));
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }
@@ -597,7 +664,8 @@ extern "C" int fea_pack_conv3x3_frag(const float* w, void* out, int Co, int Ci, 
     FEA_CHECK(w && out && Co > 0 && Ci > 0 && dtype == FEA_BF16, FEA_E_BADARG, "fea_pack_conv3x3_frag: bad args (bf16 only)");
     FEA_CHECK(Co % 64 == 0 && Ci % 64 == 0, FEA_E_UNSUPPORTED_SHAPE, "fea_pack_conv3x3_frag: channels must be multiples of 64");
     const long long total = (long long)9 * Co * Ci;
-    hipLaunchKernelGGL((pack_conv3x3_kernel<__bf16>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)out, Co, Ci, dgrad, 1);
+    FEA_CHECK(total < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "fea_pack_conv3x3_frag: %lld elements", total);
+    hipLaunchKernelGGL((pack_conv3x3_kernel<__bf16>), GRID1D(total / 9, 256), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)out, Co, Ci, dgrad, 1);
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }
@@ -623,8 +691,30 @@ extern "C" int fea_pack_conv3x3_first(const float* w, void* out, int Co, int C, 
 extern "C" int fea_pack_upconv2x2(const float* w, void* out, int Ci, int Co, int bwd, int dtype, void* stream) {
     FEA_CHECK(w && out && Ci > 0 && Co > 0 && Ci % 64 == 0 && Co % 64 == 0, FEA_E_BADARG, "fea_pack_upconv2x2: bad args");
     const long long total = (long long)4 * Ci * Co;
+    FEA_CHECK(total < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "fea_pack_upconv2x2: %lld elements", total);
     DT_SWITCH(dtype, "fea_pack_upconv2x2",
               hipLaunchKernelGGL((pack_upconv_kernel<T>), GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, w, (T*)out, Ci, Co, bwd));
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+// blocks of 256 elements that job (kind, a, b, c) needs; kinds: 0 fea_pack_conv3x3(Co, Ci, dgrad), 1 fea_pack_conv3x3_frag(Co, Ci,
+// dgrad), 2 fea_pack_upconv2x2(Ci, Co, bwd), 3 fea_pack_conv3x3_first(Co, C)
+extern "C" int fea_pack_job_blocks(int kind, int a, int b, int c) {
+    long long total;
+    if (kind == 0 || kind == 1) total = (long long)a * b;                 // one thread per 3x3 filter
+    else if (kind > 3 || kind < 0) return FEA_E_BADARG;
+    else if (kind == 2) total = (long long)4 * a * b;
+    else if (kind == 3) total = (long long)((9 * b + 31) / 32) * a * 32;
+    else return FEA_E_BADARG;
+    if (a <= 0 || b <= 0 || total * (kind <= 1 ? 9 : 1) >= (1ll << 31)) return FEA_E_BADARG;
+    return (int)((total + 255) / 256);
+}
+
+extern "C" int fea_pack_batch(const void* jobs_dev, int njobs, int nblocks, int dtype, void* stream) {
+    FEA_CHECK(jobs_dev && njobs > 0 && njobs <= 64 && nblocks > 0, FEA_E_BADARG, "fea_pack_batch: bad args (1..64 jobs)");
+    DT_SWITCH(dtype, "fea_pack_batch",
+              hipLaunchKernelGGL((pack_batch_kernel<T>), dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs_dev, njobs));
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }

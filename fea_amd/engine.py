@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import struct
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -222,6 +223,10 @@ class UNetEngine:
         # the module leaves eval mode, a parameter's version/storage changes or
         # invalidate() is called.
         self._gen = 0
+        # the packs a training step made one by one, replayed by the following steps in one launch (_pack_all)
+        self.batch_packs = os.environ.get("FEA_AMD_BATCH_PACKS", "1") != "0"
+        self._pack_jobs: Dict[str, tuple] = {}
+        self._pack_table = None
         # FEA_AMD_WGRAD_STREAM=1: weight-gradient kernels run on a second stream beside the BatchNorm-backward kernels
         # of the following layers.  Off by default: the kernels do co-run (kernel trace), but the step is no shorter
         # (85.2 vs 85.4 ms) -- the shallow levels' weight gradients are themselves HBM-heavy (2.2 TB/s), so the two
@@ -303,6 +308,8 @@ class UNetEngine:
         self.grad_views = {n: self.flat_grad[o:o + k].view(params[n].shape) for n, (o, k) in self.grad_offsets.items()}
 
     # -------------------------------------------------------------- packing
+    _PACK_KINDS = {"fea_pack_conv3x3": 0, "fea_pack_conv3x3_frag": 1, "fea_pack_upconv2x2": 2, "fea_pack_conv3x3_first": 3}
+
     def _pack(self, key: str, param: torch.nn.Parameter, numel: int, fn: str, *args):
         ver = (self._gen, param._version, param.data_ptr())
         buf = self.packed.get(key)
@@ -313,7 +320,46 @@ class UNetEngine:
         if self.packed_ver[key] != ver:
             L.call(fn, param.detach(), buf, *args, self.code, L.stream_ptr())
             self.packed_ver[key] = ver
+            kind = self._PACK_KINDS.get(fn)
+            if kind is not None and self.batch_packs and key not in self._pack_jobs:
+                # a pack this training step needed one by one: the next step makes it in the batched launch
+                a, b = args[0], args[1]
+                c = args[2] if len(args) > 2 else 0
+                self._pack_jobs[key] = (key.split("/")[0] + ".weight", buf, kind, a, b, c)
+                self._pack_table = None
         return buf
+
+    def _pack_all(self):
+        """Training mode re-packs every weight once per step (~43 tensors, most of them far smaller than a launch is
+        long): replay the packs the previous steps made, in ONE launch (`fea_pack_batch`).  Jobs are keyed like the pack
+        cache; a job whose parameter or buffer is no longer the recorded one drops out and is re-learned."""
+        jobs, P = self._pack_jobs, self._P
+        if not jobs:
+            return
+
+        def usable(k, job):
+            p = P.get(job[0])
+            return (self.packed.get(k) is job[1] and p is not None and p.device == self.device
+                    and p.dtype == torch.float32 and p.is_contiguous())
+        stale = [k for k, job in jobs.items() if not usable(k, job)]
+        for k in stale:
+            del jobs[k]
+            self._pack_table = None
+        if not jobs or len(jobs) > 64:
+            return
+        ptrs = tuple(P[job[0]].data_ptr() for job in jobs.values())      # the tensors THIS forward uses (a replica's own)
+        if self._pack_table is None or self._pack_table[0] != ptrs:
+            recs, first = [], 0
+            for src, (_pn, buf, kind, a, b, c) in zip(ptrs, jobs.values()):
+                recs.append(struct.pack("<QQiiiiii", src, buf.data_ptr(), kind, a, b, c, first, 0))
+                first += L.call("fea_pack_job_blocks", kind, a, b, c)
+            table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(self.device)
+            self._pack_table = (ptrs, table, len(recs), first)
+        _, table, n, nblocks = self._pack_table
+        L.call("fea_pack_batch", table, n, nblocks, self.code, L.stream_ptr())
+        for k, job in jobs.items():
+            p = P[job[0]]
+            self.packed_ver[k] = (self._gen, p._version, p.data_ptr())
 
     def invalidate(self):
         """Forget packed weights (call after parameters were changed in place)."""
@@ -418,6 +464,8 @@ class UNetEngine:
         pl = self.plan(N, H, W)
         P, B = self._params(), self._bufs()
         self._P, self._B = P, B
+        if training and self.batch_packs:
+            self._pack_all()
         pl.P = P                                  # the tensors this forward used (a DataParallel replica's own copies)
         S = L.stream_ptr()
         code = self.code

@@ -77,6 +77,17 @@ int fea_pack_conv3x3_im2col(const float* w, void* out, int Co, int C, int Kpad, 
  * bwd-data: out[ab*(Co/CK)+chunk][ci][j] = w[ci][chunk*CK+j][a][b] (GEMM N = Ci)  */
 int fea_pack_upconv2x2(const float* w, void* out, int Ci, int Co, int bwd, int dtype, void* stream);
 
+/* All weight packs of a training step in one launch.  No counterpart in the reference (cuDNN takes nn.Conv2d's OIHW
+ * weights as they are, models.py:10-24): the packs above exist because the kernels here want GEMM-ordered bf16 copies,
+ * and a step re-makes ~43 of them, most far smaller than a launch is long.  jobs_dev: device array of njobs (1..64)
+ * FeaPackJob in ascending first_block order; job i owns blocks [first_block_i, first_block_i + fea_pack_job_blocks(...));
+ * nblocks = their sum.  kind 0: fea_pack_conv3x3(a=Co, b=Ci, c=dgrad); 1: fea_pack_conv3x3_frag(Co, Ci, dgrad);
+ * 2: fea_pack_upconv2x2(a=Ci, b=Co, c=bwd); 3: fea_pack_conv3x3_first(a=Co, b=C).  Results are bit-identical to the
+ * single calls. */
+typedef struct FeaPackJob { const float* src; void* dst; int kind, a, b, c, first_block, reserved; } FeaPackJob;
+int fea_pack_job_blocks(int kind, int a, int b, int c);
+int fea_pack_batch(const void* jobs_dev, int njobs, int nblocks, int dtype, void* stream);
+
 /* First layer, bf16 fast path: enc1[0] = Conv2d(in_channels,64,3,padding=1) (models.py:10,28)
  * straight from the fp32 NCHW input (9*C <= 64): the im2col gather happens inside the kernel.
  * Pack: out[ks][co/16][lane][8] bf16, (9C+31)/32 * Co * 32 elements. */

@@ -717,3 +717,39 @@ def test_large_partial_tables_are_folded_correctly():
     L.call("fea_reduce_partials_n", part.to(DEV), rows, 128, 32, 0, out, S())
     torch.cuda.synchronize()
     assert rel_l2(out, part[:, :32, 0].double().sum(0).float()) < 1e-6
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_pack_batch_equals_the_single_pack_calls(dt):
+    """fea_pack_batch (one launch for all weight packs of a step) against fea_pack_conv3x3 / _frag / _upconv2x2 / _first
+    called one by one on the same weights: bit-identical buffers."""
+    import struct
+    g = torch.Generator().manual_seed(11)
+    code = L.BF16 if dt == torch.bfloat16 else L.F32
+    jobs = [("fea_pack_conv3x3", 0, (128, 64, 0), torch.randn(128, 64, 3, 3, generator=g)),
+            ("fea_pack_conv3x3", 0, (128, 64, 1), torch.randn(128, 64, 3, 3, generator=g)),
+            ("fea_pack_upconv2x2", 2, (128, 64, 0), torch.randn(128, 64, 2, 2, generator=g)),
+            ("fea_pack_upconv2x2", 2, (128, 64, 1), torch.randn(128, 64, 2, 2, generator=g))]
+    if dt == torch.bfloat16:
+        jobs += [("fea_pack_conv3x3_frag", 1, (64, 128, 0), torch.randn(64, 128, 3, 3, generator=g)),
+                 ("fea_pack_conv3x3_frag", 1, (64, 64, 1), torch.randn(64, 64, 3, 3, generator=g)),
+                 ("fea_pack_conv3x3_first", 3, (64, 3), torch.randn(64, 3, 3, 3, generator=g))]
+    S = L.stream_ptr()
+    recs, first, keep = [], 0, []
+    for fn, kind, args, w in jobs:
+        wd = w.to(DEV)
+        numel = ((9 * args[1] + 31) // 32) * 64 * 32 if kind == 3 else w.numel()
+        one = torch.zeros(numel, dtype=dt, device=DEV)
+        many = torch.zeros(numel, dtype=dt, device=DEV)
+        L.call(fn, wd, one, *args, code, S)
+        a, b = args[0], args[1]
+        c = args[2] if len(args) > 2 else 0
+        recs.append(struct.pack("<QQiiiiii", wd.data_ptr(), many.data_ptr(), kind, a, b, c, first, 0))
+        first += L.call("fea_pack_job_blocks", kind, a, b, c)
+        keep.append((fn, wd, one, many))
+    table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(DEV)
+    L.call("fea_pack_batch", table, len(recs), first, code, S)
+    torch.cuda.synchronize()
+    for fn, _w, one, many in keep:
+        assert torch.equal(one.view(torch.int16 if dt == torch.bfloat16 else torch.int32),
+                           many.view(torch.int16 if dt == torch.bfloat16 else torch.int32)), fn

@@ -712,3 +712,28 @@ def test_clip_adamw_steps_on_autograd_accumulated_gradients():
     assert torch.equal(ma.enc1[0].weight, frozen)
     for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
         assert torch.allclose(pa, pb, rtol=2e-6, atol=2e-7), (k, (pa - pb).abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_batched_weight_packs_are_bit_identical_to_single_packs(dtype):
+    """From the second training step on, the engine re-packs all weights in one launch (fea_pack_batch, replaying the packs
+    the first step made one by one).  Same losses and parameters, to the bit, as with the batching switched off."""
+    x, tgt = O.synthetic_batch(2, 64, 64, seed=43)
+    x, tgt = x.cuda(), tgt.cuda()
+    res = []
+    for batch in (False, True):
+        torch.manual_seed(17)
+        m = fea_amd.FloorPlanSegmentationModel(compute_dtype=dtype).cuda()
+        tr = UNetTrainer(m)
+        tr.eng.batch_packs = batch
+        losses = [tr.step(x, tgt).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        if batch:
+            assert tr.eng._pack_table is not None and tr.eng._pack_table[2] >= 30      # conv + transposed-conv packs, both directions
+        else:
+            assert not tr.eng._pack_jobs
+        res.append((losses, [p.detach().clone() for p in m.parameters()]))
+    for la, lb in zip(res[0][0], res[1][0]):
+        assert torch.equal(la, lb)
+    for pa, pb in zip(res[0][1], res[1][1]):
+        assert torch.equal(pa, pb)
