@@ -8,6 +8,7 @@ bf16), where the CPU oracle would take minutes per pass:
   * linearity of backward in the upstream gradient: backward(2*dl) == 2*backward(dl) exactly
     (scaling by a power of two commutes with every rounding on the path);
   * eval-mode batch independence: logits of the 64-batch == logits of its two halves;
+  * the fused head + loss path (what bench.py times) against the separate head, loss and head-backward kernels;
   * BatchNorm: the batch statistics the conv epilogue accumulated reproduce mean / var of
     the stored pre-BN tensor.
 """
@@ -90,3 +91,35 @@ def test_batch_statistics_match_the_stored_pre_bn_tensor(setup):
         assert torch.allclose(cf["mean"], mean, rtol=2e-3, atol=2e-3 * float(var.sqrt().mean())), name
         assert torch.allclose(cf["invstd"], torch.rsqrt(var + 1e-5), rtol=5e-3), name
     m.load_state_dict(state)
+
+
+def test_fused_head_loss_path_agrees_with_the_separate_kernels_at_full_size(setup):
+    """The path bench.py times forms the logits inside the loss kernels (matrix-pipe form, fp32 weights and dlogits as
+    hi + lo bf16 pairs).  Against head -> fp32 logits -> loss -> dlogits -> head backward on the same forward: the loss to
+    2e-5 relative (documented bound of the fused form, tests/test_kernels_gpu.py), every parameter gradient to 2e-3 L2-relative
+    (both paths round the head's input gradient to bf16 once; everything behind it is the same kernels), and the fused
+    path itself bit-identical when repeated."""
+    m, x, t = setup
+    eng = m._engine()
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    logits = eng.forward(x, True).clone()
+    loss_ref, dl = Fn.bce_dice_loss_and_grad(logits, t)
+    eng.backward(dl)
+    torch.cuda.synchronize()
+    g_ref, loss_ref = eng.flat_grad.clone(), loss_ref.clone()
+    fused = []
+    for _ in range(2):
+        m.load_state_dict(state)
+        eng.forward(x, True, head=False)
+        eng.backward(None, target=t)
+        torch.cuda.synchronize()
+        fused.append((eng._last[0].loss.clone(), eng.flat_grad.clone()))
+    m.load_state_dict(state)
+    assert torch.equal(fused[0][0], fused[1][0]) and torch.equal(fused[0][1], fused[1][1])
+    assert abs(float(fused[0][0]) - float(loss_ref)) <= 2e-5 * abs(float(loss_ref))
+    gnorm = float(g_ref.norm())
+    for name, (off, numel) in eng.grad_offsets.items():
+        a, b = fused[0][1][off:off + numel], g_ref[off:off + numel]
+        # (the bias of a conv in front of a train-mode BatchNorm has a gradient of exactly zero in real arithmetic: what
+        # both paths hold there is rounding noise of ~1e-9, hence the absolute term)
+        assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-6 * gnorm, (name, float((a - b).norm()), float(b.norm()))
