@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     };
     auto issue_piece = [&](__amdgpu_buffer_rsrc_t rs, int toff, unsigned edge, int stage, auto ic) {
         constexpr int i = decltype(ic)::value;
-        const unsigned f = ((i < 6 ? fl0 >> (5 * i) : fl1 >> (5 * (i - 6))) & edge) & 31u;
+        // bit 5 of `edge` = nothing follows this stage: every lane (interior ones too) takes the out-of-range offset, so the
+        // stage that is never consumed costs no memory traffic
+        const unsigned f = (((i < 6 ? fl0 >> (5 * i) : fl1 >> (5 * (i - 6))) & edge) & 31u) | (edge >> 5);
         const int voff = f ? (int)0xfffffff0u : toff + rel[i];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + stage * P_STAGE + (4 * i + wave) * 1024), 16, voff, 0, 0, P_AUX_X);
     };
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     if (tid < 64) blds[tid] = ((EPI == 0 || EPI == 3) && g.bias) ? g.bias[half * 64 + tid] : 0.f;
     __syncthreads();
     f32x4 S[2], Q[2];                 // EPI 0: sum y, sum y^2 of channels cbase + 16 n + 4 q + e
-    float a0[8], a1[8], csc[8], csh[8];   // EPI 2: channels cbase + chl + j
+    float a0[8], a1[8], csc[8], csh[8], cmn[8];   // EPI 2: channels cbase + chl + j
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         S[n] = f32x4{0.f, 0.f, 0.f, 0.f}; Q[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
         a0[j] = 0.f; a1[j] = 0.f;
         csc[j] = EPI == 2 ? g.bn_scale[cbase + chl + j] : 0.f;
         csh[j] = EPI == 2 ? g.bn_shift[cbase + chl + j] : 0.f;
+        cmn[j] = EPI == 2 ? g.bn_mean[cbase + chl + j] : 0.f;
     }
     long long ybn_lane = 0;
     char* const ylds = smem + 2 * P_STAGE + wave * 8192;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
         const bool more = (C + 1 < NCH) || (t + 1 < t1);
         const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(more ? n2 : ni);
         const int ntoff = tile_off(x2, y2, (C + 1) % NCH);
-        const unsigned nedge = more ? tile_edge(x2, y2) : 31u;          // nothing follows: every lane reads "padding" (zeros)
+        const unsigned nedge = more ? tile_edge(x2, y2) : 63u;          // nothing follows: no lane reads memory (issue_piece), the stage is zero-filled
         if constexpr (EPI == 2 && C == NCH - 1) {
             // this tile's pre-BN activations, the 64-byte rows this wave will read itself: 16 pixels x 64 B per piece
             const __bf16* yb = g.ybn + (long long)ni * g.ybn_img_stride + ((long long)(ty * P_TH) * W + tx * P_TW) * g.ldybn + ybn_lane;
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
                     for (int j = 0; j < 8; ++j) {
                         const float yf = (float)yy[j];
                         const float gg = __builtin_fmaf(yf, csc[j], csh[j]) > 0.f ? (float)dd[j] : 0.f;
-                        a0[j] += gg; a1[j] = __builtin_fmaf(gg, yf, a1[j]);
+                        a0[j] += gg; a1[j] = __builtin_fmaf(gg, yf - cmn[j], a1[j]);
                     }
                 }
             }
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
                 const bf16x8 dd = __builtin_bit_cast(bf16x8, outv);
                 const float yf = (float)yyv[j];
                 const float gg = __builtin_fmaf(yf, csc[j], csh[j]) > 0.f ? (float)dd[j] : 0.f;
-                a0[j] += gg; a1[j] = __builtin_fmaf(gg, yf, a1[j]);
+                a0[j] += gg; a1[j] = __builtin_fmaf(gg, yf - cmn[j], a1[j]);
             }
         }
     };
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
         const bool more = t + 1 < t1;
         const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(more ? n2 : ni);
         const int ntoff = tile_off(x2, y2, 0);
-        const unsigned nedge = more ? tile_edge(x2, y2) : 31u;          // nothing follows: zeros (the ring still reads that stage ahead)
+        const unsigned nedge = more ? tile_edge(x2, y2) : 63u;          // nothing follows: no lane reads memory; zeros land (the ring still reads that stage ahead)
         __bf16* const yt = g.y + (long long)ni * g.y_img_stride + ((long long)(ty * P_TH) * W + tx * P_TW) * g.ldy + y_lane;
         if constexpr (EPI == 2) y_pieces(std::integral_constant<int, 0>{});
         // first half: the next tile's 11 DMA pieces behind slots 1, 3, .. 21; from slot 24 on the previous tile's second-half epilogue
@@ -613,9 +616,9 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
             for (int o = 1; o < 16; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
             if (r16 == 0) {
                 const int ch = cbase + chl + j;
-                // sum g*xhat = invstd * (sum g*y - mean * sum g)
+                // sum g*xhat = invstd * sum g*(y - mean): centred per element, so |mean| >> std of y does not cancel
                 float* dst = g.red_part + ((long long)row * g.CoutTot + ch) * 2;
-                dst[0] = s0; dst[1] = g.bn_invstd[ch] * (s1 - g.bn_mean[ch] * s0);
+                dst[0] = s0; dst[1] = g.bn_invstd[ch] * s1;
             }
         }
     }

@@ -681,13 +681,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
         if constexpr (EPI == 2) {
             // thread -> fixed channel chunk c = tid % CPR, pixels tid / CPR + i * (256 / CPR)
             const int c = tid % CPR;
-            // 7 VALU per element: sum g and sum g*y are accumulated, sum g*xhat = invstd * (sum g*y - mean * sum g) is formed
-            // once per tile and channel at the end (as in conv_p.hip); relu'(bn(y)) = [y*scale + shift > 0] needs no max
-            float csc[8], csh[8], a0[8], a1[8];
+            // 8 VALU per element: sum g and sum g*(y - mean) are accumulated (centred per element: with |mean| >> std of y
+            // the difference sum g*y - mean * sum g would cancel in fp32), the invstd factor is applied once per tile and
+            // channel at the end (as in conv_p.hip); relu'(bn(y)) = [y*scale + shift > 0] needs no max
+            float csc[8], csh[8], cmn[8], a0[8], a1[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ch = cout0 + c * 8 + j;
-                csc[j] = g.bn_scale[ch]; csh[j] = g.bn_shift[ch];
+                csc[j] = g.bn_scale[ch]; csh[j] = g.bn_shift[ch]; cmn[j] = g.bn_mean[ch];
                 a0[j] = 0.f; a1[j] = 0.f;
             }
             const T* __restrict__ yb = (const T*)g.ybn + (long long)n_img * H * W * g.ldybn + cout0 + c * 8;
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
                         for (int j = 0; j < 8; ++j) {
                             const float yf = (float)yy[j];
                             const float gg = __builtin_fmaf(yf, csc[j], csh[j]) > 0.f ? (float)dv[j] : 0.f;   // bn_act(y) > 0 (elementwise.hip)
-                            a0[j] += gg; a1[j] = __builtin_fmaf(gg, yf, a1[j]);
+                            a0[j] += gg; a1[j] = __builtin_fmaf(gg, yf - cmn[j], a1[j]);
                         }
                     }
                 }
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
 #pragma unroll
                 for (int w_ = 0; w_ < 4; ++w_) { s0 += st[(w_ * BN + tid) * 2]; s1 += st[(w_ * BN + tid) * 2 + 1]; }
                 float* dst = g.red_part + ((long long)ptile * g.Cout + cout0 + tid) * 2;
-                dst[0] = s0; dst[1] = g.bn_invstd[cout0 + tid] * (s1 - g.bn_mean[cout0 + tid] * s0);
+                dst[0] = s0; dst[1] = g.bn_invstd[cout0 + tid] * s1;
             }
         } else {
 #pragma unroll

@@ -140,6 +140,12 @@ class FloorPlanSegmentationModel(nn.Module):
             device = torch.device("cuda", torch.cuda.current_device())
         key = (str(device), self.compute_dtype)
         eng = self._engs.get(key)
+        if eng is None and device.type == "cuda":
+            # an engine handed out while the module was still on the CPU (UNetTrainer(model) before model.cuda()) binds
+            # its device at its first forward: it becomes this device's engine, not a second one with plans of its own
+            stale = self._engs.get(("cpu", self.compute_dtype))
+            if stale is not None and (stale.device is None or stale.device == device):
+                eng = self._engs[key] = self._engs.pop(("cpu", self.compute_dtype))
         if eng is None:
             eng = UNetEngine(self, self.compute_dtype)
             self._engs[key] = eng

@@ -57,8 +57,12 @@ class GradBuckets:
 
     def _reduce(self, s, e):
         sl = self.eng.flat_grad[s:e]
-        dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
-        sl.mul_(1.0 / self.world)
+        if self.on_gpu:
+            # RCCL averages inside the collective: no second pass over the bucket on the communication stream
+            dist.all_reduce(sl, op=dist.ReduceOp.AVG, group=self.group)
+        else:                                    # gloo has no AVG
+            dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
+            sl.mul_(1.0 / self.world)
 
     def on_ready(self, name: str):
         i = self.trigger.get(name)
@@ -123,9 +127,15 @@ class UNetTrainer:
         names = [n for n, _ in self.model.named_parameters()]
         for n, p in zip(names, self.params):
             p.grad = self.eng.grad_views[n]
+        self._bound = [(p, self.eng.grad_views[n].data_ptr()) for n, p in zip(names, self.params)]
         if self.distributed and self.buckets is None:
             self.buckets = GradBuckets(self.eng)
         self._grads_bound = True
+
+    def _grads_still_bound(self) -> bool:
+        """False after `opt.zero_grad()` / `model.zero_grad()` (set_to_none=True is torch's default) or any other
+        re-assignment of p.grad: the step would then run forward and backward and update nothing."""
+        return all(p.grad is not None and p.grad.data_ptr() == ptr for p, ptr in self._bound)
 
     def step(self, x: torch.Tensor, target_u8: torch.Tensor):
         """One optimisation step; returns the loss as a 1-element device tensor."""
@@ -136,9 +146,13 @@ class UNetTrainer:
             else bool(self.fuse_head_loss) if isinstance(self.fuse_head_loss, bool)
             else (self.eng.dtype == torch.bfloat16 and (x.shape[2] * x.shape[3]) % 16 == 0))
         logits = self.eng.forward(x, True, head=not fused)
-        if not self._grads_bound:
+        if not self._grads_bound or not self._grads_still_bound():
             self.eng._ensure_device(x)
             self._bind_grads()
+        if isinstance(self.opt, ClipAdamW):
+            # this step's backward is the one the optimiser steps on, whatever else ran on the engine since the last
+            # step (a gradient check, a module-path backward)
+            self.opt._bw_seen = self.eng.backward_count
         if fused:
             # head + BCE/Dice + their backward fused: the logits never go to HBM (writes p.grad: views of the flat buffer)
             self.eng.backward(None, target=target_u8)

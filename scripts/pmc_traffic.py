@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one pass each, as
-MI355X_MICROARCH.md prescribes) -> profiles/r2_pmc_hbm_traffic.json, which bench.py reads for `roofline.traffic`.
+MI355X_MICROARCH.md prescribes) -> profiles/r3_pmc_hbm_traffic.json, which bench.py reads for `roofline.traffic`.
 
     python scripts/pmc_traffic.py FETCH.csv WRITE.csv "train batch 64 512x512 bf16" STEPS [out.json]
 
@@ -52,7 +52,7 @@ def per_kernel(path, counter):
 
 def main():
     fetch_csv, write_csv, workload, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
+    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.json")
     ft, fc = per_kernel(fetch_csv, "FETCH_SIZE")
     wt, wc = per_kernel(write_csv, "WRITE_SIZE")
     kernels = {}

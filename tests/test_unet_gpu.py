@@ -737,3 +737,46 @@ def test_batched_weight_packs_are_bit_identical_to_single_packs(dtype):
         assert torch.equal(la, lb)
     for pa, pb in zip(res[0][1], res[1][1]):
         assert torch.equal(pa, pb)
+
+
+def test_trainer_survives_zero_grad_and_a_foreign_backward():
+    """after `opt.zero_grad()` (set_to_none=True is torch's default) p.grad is None everywhere; the trainer must
+    re-bind its gradient views instead of running forward + backward and updating nothing.  A backward that someone else
+    ran on the same engine between two steps (a gradient check through the module) must not make the next step raise."""
+    x, tgt = O.synthetic_batch(2, 32, 32, seed=51)
+    x, tgt = x.cuda(), tgt.cuda()
+    res = []
+    for disturb in (False, True):
+        torch.manual_seed(19)
+        m = fea_amd.FloorPlanSegmentationModel(compute_dtype="fp32").cuda()
+        tr = UNetTrainer(m, dict(learning_rate=1e-3))
+        tr.step(x, tgt)
+        if disturb:
+            tr.opt.zero_grad()                                    # p.grad = None
+            assert all(p.grad is None for p in m.parameters())
+            with torch.enable_grad():                             # a module-path backward on the same engine
+                m(x).sum().backward()
+            tr.opt.zero_grad()
+        tr.step(x, tgt)
+        torch.cuda.synchronize()
+        res.append([p.detach().clone() for p in m.parameters()])
+    moved = sum(float((a - b).abs().sum()) for a, b in zip(res[0], res[1]))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert moved == 0.0
+
+
+def test_trainer_built_before_cuda_uses_one_engine():
+    """UNetTrainer(model) before model.cuda() must not leave a second ('cpu') engine with plans of its own."""
+    torch.manual_seed(20)
+    m = fea_amd.FloorPlanSegmentationModel(compute_dtype="bf16")
+    tr = UNetTrainer(m)
+    m.cuda()
+    tr.params = list(m.parameters())
+    x, tgt = O.synthetic_batch(2, 32, 32, seed=52)
+    tr.step(x.cuda(), tgt.cuda())
+    m.eval()
+    with torch.no_grad():
+        m(x.cuda())
+    assert len(m._engs) == 1 and next(iter(m._engs.values())) is tr.eng
+    assert tr.eng.device is not None and tr.eng.device.type == "cuda"
