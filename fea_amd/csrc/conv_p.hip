@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     // idle time and no extra registers.  With K = 1152 both LDS stages hold the current tile: no room to run ahead.
     constexpr bool OVL = NCH == 1 && EPI != 3;
     constexpr int YB = EPI == 2 ? 4 * 8192 : 0;        // per-wave private y tiles (128 px x 64 B)
-    __shared__ __attribute__((aligned(128))) char smem[2 * P_STAGE + YB + 256];
+    // EPI 2 with K = 1152: scale / shift / mean of the 64-column group live in LDS and are read per tile (24 registers that are
+    // only live in the epilogue, where the A ring is dead) -- as persistent registers the kernel spilled 30 VGPRs
+    constexpr bool COEF_LDS = EPI == 2 && NCH == 2;
+    __shared__ __attribute__((aligned(128))) char smem[2 * P_STAGE + YB + 256 + (COEF_LDS ? 768 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform: LDS-DMA bases stay scalar
@@ -197,6 +200,13 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     // it occupies registers only for the first k-step of each tile
     float* const blds = reinterpret_cast<float*>(smem + 2 * P_STAGE + YB);
     if (tid < 64) blds[tid] = ((EPI == 0 || EPI == 3) && g.bias) ? g.bias[half * 64 + tid] : 0.f;
+    float* const clds = blds + 64;                // [3][64]: scale, shift, mean (COEF_LDS)
+    if constexpr (COEF_LDS) {
+        if (tid < 192) {
+            const float* src = tid < 64 ? g.bn_scale : (tid < 128 ? g.bn_shift : g.bn_mean);
+            clds[tid] = src[half * 64 + (tid & 63)];
+        }
+    }
     __syncthreads();
     f32x4 S[2], Q[2];                 // EPI 0: sum y, sum y^2 of channels cbase + 16 n + 4 q + e
     float a0[8], a1[8], csc[8], csh[8], cmn[8];   // EPI 2: channels cbase + chl + j
@@ -207,13 +217,22 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         a0[j] = 0.f; a1[j] = 0.f;
-        csc[j] = EPI == 2 ? g.bn_scale[cbase + chl + j] : 0.f;
-        csh[j] = EPI == 2 ? g.bn_shift[cbase + chl + j] : 0.f;
-        cmn[j] = EPI == 2 ? g.bn_mean[cbase + chl + j] : 0.f;
+        csc[j] = (EPI == 2 && !COEF_LDS) ? g.bn_scale[cbase + chl + j] : 0.f;
+        csh[j] = (EPI == 2 && !COEF_LDS) ? g.bn_shift[cbase + chl + j] : 0.f;
+        cmn[j] = (EPI == 2 && !COEF_LDS) ? g.bn_mean[cbase + chl + j] : 0.f;
     }
-    long long ybn_lane = 0;
+    // EPI 2: the y rows arrive by LDS-DMA buffer loads (descriptor = one image): a lane's byte offset inside the tile is a
+    // constant, the tile origin and the row of piece m are wave-uniform (scalar offset operand)
+    int ybn_lane = 0;
     char* const ylds = smem + 2 * P_STAGE + wave * 8192;
-    if constexpr (EPI == 2) ybn_lane = ((long long)(wm * 4) * W) * g.ldybn + cbase;
+    if constexpr (EPI == 2) ybn_lane = (((wm * 4) * W + (lane >> 2)) * g.ldybn + cbase + (lane & 3) * 8) * 2;
+    auto y_rsrc = [&](int n_img) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(g.ybn + (long long)n_img * g.ybn_img_stride), 0, (int)(g.ybn_img_stride * 2), 0x00020000);
+    };
+    auto y_piece = [&](__amdgpu_buffer_rsrc_t rs, int tile_byte_off, int m) {
+        const int soff = tile_byte_off + (((m >> 1) * W + (m & 1) * 16) * g.ldybn) * 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(ylds + m * 1024), 16, ybn_lane, soff, 0, P_AUX_Y);
+    };
 
     f32x4 acc[8][2];
     // the first k-step of a tile takes the bias as its C operand: the accumulators are never re-initialised
@@ -303,12 +322,10 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
         const unsigned nedge = more ? tile_edge(x2, y2) : 63u;          // nothing follows: no lane reads memory (issue_piece), the stage is zero-filled
         if constexpr (EPI == 2 && C == NCH - 1) {
             // this tile's pre-BN activations, the 64-byte rows this wave will read itself: 16 pixels x 64 B per piece
-            const __bf16* yb = g.ybn + (long long)ni * g.ybn_img_stride + ((long long)(ty * P_TH) * W + tx * P_TW) * g.ldybn + ybn_lane;
+            const __amdgpu_buffer_rsrc_t yrs = y_rsrc(ni);
+            const int ytile = (((ty * P_TH) * W + tx * P_TW) * g.ldybn) * 2;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const __bf16* src = yb + ((long long)(m >> 1) * W + (m & 1) * 16 + (lane >> 2)) * g.ldybn + (lane & 3) * 8;
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ylds + m * 1024), 16, 0, P_AUX_Y);
-            }
+            for (int m = 0; m < 8; ++m) y_piece(yrs, ytile, m);
         }
         mma_stage(cc, sc_, [&](auto stc, auto mc) {
             constexpr int step = decltype(stc)::value, m = decltype(mc)::value, piece = step * 4 + (m >> 1);
@@ -356,6 +373,12 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
                     }
                 }
             }
+            float lsc[8], lsh[8], lmn[8];
+            if constexpr (COEF_LDS) {
+                const float* cf = clds + wn * 32 + chl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { lsc[j] = cf[j]; lsh[j] = cf[64 + j]; lmn[j] = cf[128 + j]; }
+            }
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 if constexpr (EPI == 0 && STATS >= 1) {
@@ -382,8 +405,9 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float yf = (float)yy[j];
-                        const float gg = __builtin_fmaf(yf, csc[j], csh[j]) > 0.f ? (float)dd[j] : 0.f;
-                        a0[j] += gg; a1[j] = __builtin_fmaf(gg, yf - cmn[j], a1[j]);
+                        const float sc_ = COEF_LDS ? lsc[j] : csc[j], sh_ = COEF_LDS ? lsh[j] : csh[j], mn_ = COEF_LDS ? lmn[j] : cmn[j];
+                        const float gg = __builtin_fmaf(yf, sc_, sh_) > 0.f ? (float)dd[j] : 0.f;
+                        a0[j] += gg; a1[j] = __builtin_fmaf(gg, yf - mn_, a1[j]);
                     }
                 }
             }
@@ -491,12 +515,10 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     };
     auto y_pieces = [&](auto hc) {      // EPI 2: this tile's pre-BN activations of one pixel half, the rows this wave reads itself
         constexpr int HALF = decltype(hc)::value;
-        const __bf16* yb = g.ybn + (long long)ni * g.ybn_img_stride + ((long long)(ty * P_TH) * W + tx * P_TW) * g.ldybn + ybn_lane;
+        const __amdgpu_buffer_rsrc_t yrs = y_rsrc(ni);
+        const int ytile = (((ty * P_TH) * W + tx * P_TW) * g.ldybn) * 2;
 #pragma unroll
-        for (int m = HALF * 4; m < HALF * 4 + 4; ++m) {
-            const __bf16* src = yb + ((long long)(m >> 1) * W + (m & 1) * 16 + (lane >> 2)) * g.ldybn + (lane & 3) * 8;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(ylds + m * 1024), 16, 0, P_AUX_Y);
-        }
+        for (int m = HALF * 4; m < HALF * 4 + 4; ++m) y_piece(yrs, ytile, m);
     };
     // stores among the first-half epilogue's micro-operations that are issued before slot `lim` of the second half
     constexpr int S0B = 8, NMB = 4 * NPER;

@@ -238,6 +238,9 @@ class UNetEngine:
         # persistent conv kernels for the shallow levels (bf16); FEA_AMD_PERSISTENT=0 selects the plain kernels (A/B runs)
         self.use_persistent = compute_dtype == torch.bfloat16 and os.environ.get("FEA_AMD_PERSISTENT", "1") != "0"
         self._p_rows_cache: Dict[tuple, int] = {}
+        # fused-BatchNorm-reduction data gradient of the 128 -> 128 layers on the persistent kernel too (round 3: its
+        # scale / shift / mean moved to LDS, no more spills); FEA_AMD_P_EPI2_128=0 selects the one-tile-per-workgroup kernel (A/B runs)
+        self.p_epi2_128 = os.environ.get("FEA_AMD_P_EPI2_128", "1") != "0"
         self.backward_count = 0        # backward passes run so far (ClipAdamW checks that it steps on one backward's gradients)
         L.load()
 
@@ -425,7 +428,7 @@ class UNetEngine:
 
     def _p_modes(self, pl: "_Plan"):
         """Per conv layer: (rows of the persistent forward kernel, rows of the persistent data-gradient kernel), 0 = not
-        served.  X.3 layers' data gradient is the fused-BatchNorm-reduction kernel, served for 64 channels only."""
+        served.  X.3 layers' data gradient is the fused-BatchNorm-reduction kernel, served for 64 and 128 channels."""
         modes = getattr(pl, "p_modes", None)
         if modes is None:
             modes = {}
@@ -435,7 +438,7 @@ class UNetEngine:
                 f0 = self._p_rows(pl.N, h, w, cin, c) if blk != "enc1" else 0
                 d0 = self._p_rows(pl.N, h, w, c, cin) if blk != "enc1" else 0
                 f3 = self._p_rows(pl.N, h, w, c, c)
-                d3 = f3 if c == 64 else 0
+                d3 = f3 if (c == 64 or (c == 128 and self.p_epi2_128)) else 0
                 modes[f"{blk}.0"], modes[f"{blk}.3"] = (f0, d0), (f3, d3)
             pl.p_modes = modes
         return modes
