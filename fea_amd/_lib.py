@@ -23,6 +23,8 @@ P, I, L, F, Z, D = c_void_p, c_int, c_longlong, c_float, c_size_t, c_double
 SIGNATURES = {
     "fea_version": (I, []),
     "fea_last_error": (c_char_p, []),
+    "fea_set_persistent_split": (I, [I]),
+    "fea_get_persistent_split": (I, []),
     "fea_im2col3x3_nchw": (I, [P, P, I, I, I, I, I, I, P]),
     "fea_nhwc_to_nchw_f32": (I, [P, I, P, I, I, I, I, I, P]),
     "fea_nchw_f32_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),

@@ -657,7 +657,7 @@ static bool c3p_plan(int N, int H, int W, int Cin, int Cout, int dtype, C3pPlan&
     if (nt >= (1ll << 30)) return false;
     p.ntiles = (int)nt;
     p.nhalf = Cout / 64;
-    int want = 256 / p.nhalf;                 // one workgroup per CU
+    int want = 256 / p.nhalf * fea_wg_split();      // one workgroup per CU (x fea_set_persistent_split when CUs may be taken away)
     if (want > p.ntiles) want = p.ntiles;
     p.tiles_per_wg = (p.ntiles + want - 1) / want;
     p.npixwg = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;

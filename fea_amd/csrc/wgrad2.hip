@@ -377,6 +377,224 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args g) {
 }
 
 // ---------------------------------------------------------------------------
+// wgrad3: the same kernel on v_mfma_f32_16x16x32_bf16 (8x32-pixel tiles only).
+//
+// Same workgroup tile (64 co x 64 ci x 9 taps over a range of 256-pixel tiles), same wave roles (wa: co half, wb: ci half,
+// waves 0-3 taps 0-4, waves 4-7 taps 5-8), same LDS image and LDS-DMA pieces as wgrad2_kernel<5, *>; the wave's 32 x 32 block
+// of a tap is four 16 x 16 accumulator tiles and a k-step is one tile row of 32 pixels (8 k-steps per tile).  Operand bytes
+// read from LDS per FLOP are unchanged; the chip holds a higher clock on the 16x16x32 form of an LDS-fed bf16 loop
+// (MI355X_MICROARCH.md, 'DVFS give-back' item 7; the persistent conv kernel measured 10-20 % between the two forms).
+//
+// Fragment of a 16-row operand tile for k = pixels 8 g .. 8 g + 7 (g = lane >> 4): two ds_read_b64_tr_b16, read t = 0 / 1
+// fetches pixels 8 g + 4 t + (li >> 2), channels 4 (li & 3) .. + 3 of the tile (li = lane & 15) and returns, transposed within
+// the 16 lanes, channel li at pixels 8 g + 4 t .. + 3.  Lanes 0-31 of one read touch 8 pixel rows {b .. b+3, b+8 .. b+11} x 32 B:
+// the XOR below (chunk bits 2, 1 <- pixel bits 1, 3; bit 0 of the chunk untouched so the 32 B stay together) puts them in
+// 8 different 32-byte bank groups for every b, i.e. for every halo shift dx.
+__device__ __forceinline__ int swzw3(int x) { return (((x >> 1) & 1) << 2) | (((x >> 3) & 1) << 1); }
+
+template <int NT> struct Wg3Frag { u32x2 a[2][2]; u32x2 b[NT][2][2]; };      // [m or n tile][read t]
+
+template <int NT> __device__ constexpr int wg3_cnt(int t) { return (4 + 4 * NT + NT - 1 - t) / NT; }
+template <int NT> __device__ constexpr int wg3_start(int t) { int s = 0; for (int u = 0; u < t; ++u) s += wg3_cnt<NT>(u); return s; }
+
+// read number R of k-step S: 0..3 = A (m tile R >> 1, half R & 1); 4 + 4 t + 2 n + hf = B of tap t, n tile n, half hf
+template <int TAP0, int NT, int S, int R>
+__device__ __forceinline__ void wg3_read(Wg3Frag<NT>& f, const uint32_t (&pa)[2][2], const uint32_t (&qa)[2][2][3]) {
+    constexpr int HW2 = 34;
+    if constexpr (R < 4) {
+        lds_tr<S * 32 * 128>(f.a[R >> 1][R & 1], pa[R >> 1][R & 1]);
+    } else {
+        constexpr int t = (R - 4) / 4, n = ((R - 4) / 2) % 2, hf = (R - 4) % 2, tap = TAP0 + t, dy = tap / 3, dx = tap % 3;
+        lds_tr<(S + dy) * HW2 * 128>(f.b[t][n][hf], qa[n][hf][dx]);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wg3_wait_ab(u32x2 (&a)[2][2], u32x2 (&b)[2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]),
+                                           "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void wg3_wait_b(u32x2 (&b)[2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+}
+
+// k-step S: fragments in `cur`; those of S + 1 are read into `nxt` between the MFMAs of this step.
+template <int TAP0, int NT, int S, typename PieceFn>
+__device__ __forceinline__ void wg3_kstep(Wg3Frag<NT>& cur, Wg3Frag<NT>& nxt, const uint32_t (&pa)[2][2], const uint32_t (&qa)[2][2][3],
+                                          f32x4 (&acc)[NT][2][2], PieceFn&& piece) {
+    constexpr int NSTEP = 8, NRD = 4 + 4 * NT;
+    constexpr bool more = S + 1 < NSTEP;
+    sfor<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        // reads issued behind the ones this tap needs: the rest of this step's (taps t + 1 ..) and the next step's so far
+        constexpr int behind = NRD - (8 + 4 * t) + (more ? wg3_start<NT>(t) : 0);
+        if constexpr (t == 0) wg3_wait_ab<(behind < 15 ? behind : 15)>(cur.a, cur.b[0]);
+        else                  wg3_wait_b<(behind < 15 ? behind : 15)>(cur.b[t]);
+        u32x4 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            af[i] = u32x4{cur.a[i][0].x, cur.a[i][0].y, cur.a[i][1].x, cur.a[i][1].y};
+            bf[i] = u32x4{cur.b[t][i][0].x, cur.b[t][i][0].y, cur.b[t][i][1].x, cur.b[t][i][1].y};
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf[ni]),
+                                                                         acc[t][mi][ni], 0, 0, 0);
+        if constexpr (more) {
+            sfor<0, wg3_cnt<NT>(t)>([&](auto rc) {
+                wg3_read<TAP0, NT, S + 1, wg3_start<NT>(t) + decltype(rc)::value>(nxt, pa, qa);
+            });
+        }
+        // the ten LDS-DMA pieces of the next tile: one per k-step behind tap 1, the last two behind tap 3 of k-steps 0 and 1
+        if constexpr (t == 1) piece(std::integral_constant<int, S>{});
+        if constexpr (t == 3 && S < 2) piece(std::integral_constant<int, 8 + S>{});
+    });
+    if constexpr (more) wg3_kstep<TAP0, NT, S + 1>(nxt, cur, pa, qa, acc, piece);
+}
+
+template <int TAP0, int NT, bool FAST>
+__device__ __forceinline__ void wg3_run(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
+                                        const int (&pdesc)[4], const int (&qdesc)[6], unsigned qfl, int wave, int t_begin, int t_end,
+                                        char* smem, const int (&pcol)[2][2], const int (&qcol)[2][2][3], int orow, int ocol) {
+    constexpr int STAGE = (256 + 352) * 128, PBYTES = 256 * 128;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    f32x4 acc[NT][2][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int ntx, nty, nn;
+    {
+        int tt = t_begin;
+        ntx = tt % g.tiles_x; tt /= g.tiles_x;
+        nty = tt % g.tiles_y; nn = tt / g.tiles_y;
+    }
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int stage = (tile - t_begin) & 1;
+        if (++ntx == g.tiles_x) { ntx = 0; if (++nty == g.tiles_y) { nty = 0; ++nn; } }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // this wave's LDS-DMA has landed; barrier: tile complete, other stage free
+        const bool has_next = tile + 1 < t_end;
+        char* dma = smem + (stage ^ 1) * STAGE;
+        const uint32_t rd = lds_base + stage * STAGE;
+        auto piece = [&](auto ic) {
+            if (has_next) wg2_issue_piece<5, decltype(ic)::value, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, ntx, nty, nn, dma);
+        };
+        uint32_t pa[2][2], qa[2][2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                pa[i][t] = rd + pcol[i][t];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) qa[i][t][dx] = rd + PBYTES + qcol[i][t][dx];
+            }
+        Wg3Frag<NT> f0, f1;
+        sfor<0, 4 + 4 * NT>([&](auto rc) { wg3_read<TAP0, NT, 0, decltype(rc)::value>(f0, pa, qa); });
+        wg3_kstep<TAP0, NT, 0>(f0, f1, pa, qa, acc, piece);
+    }
+    __syncthreads();                     // every wave is done reading the stages
+    float* ot = reinterpret_cast<float*>(smem);       // [64 m][64 n][9]
+    const int gi = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int mr = orow + mi * 16 + 4 * gi + e;
+                    ot[(mr * 64 + ocol + ni * 16) * 9 + TAP0 + t] = acc[t][mi][ni][e];
+                }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(512, 2) void wgrad3_kernel(const Wgrad2Args g) {
+    constexpr int TW = 32, TH = 8, HW2 = TW + 2;
+    constexpr int QROWS = 352;
+    constexpr int PBYTES = 256 * 128, QBYTES = QROWS * 128, STAGE = PBYTES + QBYTES;
+    constexpr int NPI = 4, NQI = 6;
+    __shared__ __attribute__((aligned(128))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = wave >> 2;
+    const int wa = (wave >> 1) & 1, wb = wave & 1;
+    const int gi = lane >> 4, li = lane & 15;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntp = g.nmt * g.nnt;
+    const int tp = lid % ntp, split = lid / ntp;
+    const int m0 = (tp / g.nnt) * 64, n0 = (tp % g.nnt) * 64;
+
+    // ---- fragment offsets -------------------------------------------------
+    int pcol[2][2], qcol[2][2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int x = 8 * gi + 4 * t + (li >> 2);
+            const int chp = wa * 32 + i * 16 + 4 * (li & 3), chq = wb * 32 + i * 16 + 4 * (li & 3);
+            pcol[i][t] = x * 128 + (((chp >> 3) ^ swzw3(x)) << 4) + (chp & 7) * 2;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int hx = x + dx;
+                qcol[i][t][dx] = hx * 128 + (((chq >> 3) ^ swzw3(hx)) << 4) + (chq & 7) * 2;
+            }
+        }
+
+    // ---- LDS-DMA descriptors (as wgrad2_kernel, with this kernel's swizzle) -------
+    int pdesc[NPI], qdesc[NQI];
+    unsigned qfl = 0;
+    {
+        const int rsub = lane >> 3, cpos = lane & 7;
+#pragma unroll
+        for (int it = 0; it < NPI; ++it) {
+            const int row = (it * 8 + wave) * 8 + rsub;
+            const int ty = row >> 5, tx = row & (TW - 1);
+            if constexpr (FAST) pdesc[it] = (ty * g.W + tx) * g.ldp * 2 + ((cpos ^ swzw3(tx)) << 4);
+            else pdesc[it] = (ty + 1) | ((tx + 1) << 8) | ((cpos ^ swzw3(tx)) << 24);
+        }
+#pragma unroll
+        for (int it = 0; it < NQI; ++it) {
+            const int row = (it * 8 + wave) * 8 + rsub;
+            const int hy = row / HW2, hx = row - hy * HW2;
+            const int inval = hy >= TH + 2 ? 1 : 0;
+            if constexpr (FAST) {
+                qdesc[it] = ((hy - 1) * g.W + (hx - 1)) * g.ldq * 2 + ((cpos ^ swzw3(hx)) << 4);
+                const unsigned f = (hy == 0 ? 1u : 0u) | (hy == TH + 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == TW + 1 ? 8u : 0u) | (inval ? 16u : 0u);
+                qfl |= f << (5 * it);
+            } else qdesc[it] = hy | (hx << 8) | (inval << 16) | ((cpos ^ swzw3(hx)) << 24);
+        }
+    }
+
+    const __bf16* __restrict__ pg = g.p + m0;
+    const __bf16* __restrict__ qg = g.q + n0;
+    const int t_begin = split * g.tiles_per_split;
+    const int t_end = min(t_begin + g.tiles_per_split, g.ntiles);
+
+    if (t_begin < t_end) {
+        int tt = t_begin;
+        const int tx = tt % g.tiles_x; tt /= g.tiles_x;
+        wg2_issue<5, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, tx, tt % g.tiles_y, tt / g.tiles_y, smem);
+    }
+    if (WG2_PRIO && kg == 1) __builtin_amdgcn_s_setprio(WG2_PRIO);
+    if (kg == 0) wg3_run<0, 5, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, t_begin, t_end, smem, pcol, qcol, wa * 32, wb * 32 + li);
+    else         wg3_run<5, 4, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, t_begin, t_end, smem, pcol, qcol, wa * 32, wb * 32 + li);
+    __syncthreads();
+    const float* ot = reinterpret_cast<const float*>(smem);
+    float* dst = g.out + (long long)split * g.out_split_stride + ((long long)m0 * g.Nn + n0) * 9;
+    for (int i = tid; i < 64 * 144; i += 512) {
+        const int row = i / 144, c4 = i - row * 144;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * 576 + c4 * 4);
+        *reinterpret_cast<f32x4*>(dst + (long long)row * g.Nn * 9 + c4 * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
 struct Wgrad2Plan { int tws, tiles_x, tiles_y, ntiles, splits, tiles_per_split, nmt, nnt; };
 
 static Wgrad2Plan wgrad2_plan(int N, int H, int W, int M, int Nn) {
@@ -388,6 +606,7 @@ static Wgrad2Plan wgrad2_plan(int N, int H, int W, int M, int Nn) {
     p.nmt = M / 64; p.nnt = Nn / 64;
     int want = 256 / (p.nmt * p.nnt);                // one workgroup per CU: fewest slabs to write and re-read
     if (want < 1) want = 1;
+    want *= fea_wg_split();                          // (x fea_set_persistent_split when CUs may be taken away)
     if (want > p.ntiles) want = p.ntiles;
     p.tiles_per_split = (p.ntiles + want - 1) / want;
     p.splits = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
@@ -422,7 +641,13 @@ int fea_wgrad2_launch(const void* dy, int lddy, const void* x, int ldx, float* d
     // whole tiles and 32-bit in-image byte offsets: the LDS-DMA pieces take the buffer-descriptor form (wg2_issue_piece)
     const int TWl = 1 << p.tws, THl = 256 / TWl;
     const bool fast = H % THl == 0 && W % TWl == 0 && (long long)(H + 2) * W * lddy * 2 < (1ll << 31) && (long long)(H + 2) * W * ldx * 2 < (1ll << 31);
-    if (p.tws == 5) { if (fast) hipLaunchKernelGGL((wgrad2_kernel<5, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((wgrad2_kernel<5, false>), grid, block, 0, s, a); }
+    // FEA_AMD_WG3=1 selects the 16x16x32 form of the 8x32-tile kernel (wgrad3_kernel).  Measured round 3, same box: correct
+    // (all weight-gradient tests) and 4-7 % SLOWER per launch (64->64 @512^2 1.225 -> 1.308 ms, 256->256 @128^2 0.948 -> 0.995;
+    // step 81.4 -> 82.5 ms): twice the MFMA issues and the same number of 8-byte transposing LDS reads make the loop
+    // issue-bound before the higher clock of the 16x16x32 form can pay.  Off by default.
+    static const bool wg3 = getenv("FEA_AMD_WG3") && getenv("FEA_AMD_WG3")[0] == '1';
+    if (p.tws == 5 && wg3) { if (fast) hipLaunchKernelGGL((wgrad3_kernel<true>), grid, block, 0, s, a); else hipLaunchKernelGGL((wgrad3_kernel<false>), grid, block, 0, s, a); }
+    else if (p.tws == 5) { if (fast) hipLaunchKernelGGL((wgrad2_kernel<5, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((wgrad2_kernel<5, false>), grid, block, 0, s, a); }
     else            { if (fast) hipLaunchKernelGGL((wgrad2_kernel<4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((wgrad2_kernel<4, false>), grid, block, 0, s, a); }
     FEA_LAUNCH_CHECK();
     if (p.splits > 1) {

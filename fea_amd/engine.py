@@ -78,7 +78,7 @@ def _table_rows(N, h, w) -> int:
     """Upper bound of the rows of a conv kernel's partial-sum table (`stats` / `part`): one per pixel tile for the
     one-tile-per-workgroup kernels, two per workgroup (at most 2 x 256, at most 2 per tile) for the persistent ones."""
     nt = L.call("fea_conv_num_tiles", N, h, w)
-    return max(nt, min(512, 2 * N * ((h + 7) // 8) * ((w + 31) // 32)))
+    return max(nt, min(512 * L.load().fea_get_persistent_split(), 2 * N * ((h + 7) // 8) * ((w + 31) // 32)))
 
 
 class _Plan:
@@ -241,6 +241,9 @@ class UNetEngine:
         # fused-BatchNorm-reduction data gradient of the 128 -> 128 layers on the persistent kernel too (round 3: its
         # scale / shift / mean moved to LDS, no more spills); FEA_AMD_P_EPI2_128=0 selects the one-tile-per-workgroup kernel (A/B runs)
         self.p_epi2_128 = os.environ.get("FEA_AMD_P_EPI2_128", "1") != "0"
+        # work-split factor of the persistent kernels (fea_set_persistent_split): FEA_AMD_PERSISTENT_SPLIT overrides the library default
+        if os.environ.get("FEA_AMD_PERSISTENT_SPLIT"):
+            L.call("fea_set_persistent_split", int(os.environ["FEA_AMD_PERSISTENT_SPLIT"]))
         self.backward_count = 0        # backward passes run so far (ClipAdamW checks that it steps on one backward's gradients)
         L.load()
 

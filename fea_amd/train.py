@@ -121,6 +121,16 @@ class UNetTrainer:
         self.buckets = None
         self.distributed = distributed
         self._grads_bound = False
+        if (distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                and not os.environ.get("FEA_AMD_PERSISTENT_SPLIT")):
+            # The all-reduce's channel kernels take CUs while backward runs.  A persistent kernel (one workgroup per CU,
+            # static tile ranges) whose workgroup finds its CU taken waits for a peer to finish: 1.6-1.8x per launch with
+            # 8-32 CUs held (scripts/cu_steal_test.py).  Four workgroups per CU's worth of tiles: 1.02-1.14x, for
+            # +0.6 % on an undisturbed step.  Set before the first forward: table and workspace sizes depend on it.
+            # (World size 1 keeps the single-GPU setting and its bit-identical results.)
+            L.call("fea_set_persistent_split", 4)
+            self.eng.plans.clear()
+            self.eng._p_rows_cache.clear()
 
     def _bind_grads(self):
         self.eng._ensure_flat_grad()

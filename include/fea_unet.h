@@ -50,6 +50,13 @@ extern "C" {
 
 int fea_version(void);
 const char* fea_last_error(void);
+/* Work-split factor of the persistent kernels (fea_conv3x3p*, fea_conv3x3_wgrad in bf16): factor x 256 workgroups of
+ * 1 / factor of the tile range each.  No counterpart in the reference (its multi-GPU mode, nn.DataParallel at
+ * train_direct.py:23-25, has no kernels of its own).  Default 1; the data-parallel trainer sets 4 so that workgroups
+ * displaced by the all-reduce's channel kernels do not serialise behind their peers.  Process-wide; set it before the
+ * first forward (table and workspace sizes, fea_conv3x3p_rows / fea_wgrad_ws_bytes, depend on it). */
+int fea_set_persistent_split(int factor);
+int fea_get_persistent_split(void);
 
 /* ---- layout / packing ---------------------------------------------------- */
 

@@ -780,3 +780,34 @@ def test_trainer_built_before_cuda_uses_one_engine():
         m(x.cuda())
     assert len(m._engs) == 1 and next(iter(m._engs.values())) is tr.eng
     assert tr.eng.device is not None and tr.eng.device.type == "cuda"
+
+
+def test_persistent_split_gives_the_same_training_step():
+    """fea_set_persistent_split(4) (what the data-parallel trainer sets so that workgroups displaced by the all-reduce's
+    kernels do not serialise): four times as many, shorter tile ranges per persistent kernel.  Same mathematics, other
+    summation grouping of the BatchNorm partial sums and weight-gradient slabs: the step agrees with split 1 to fp32
+    rounding of those sums, and the kernel-level parity tests hold under it."""
+    from fea_amd import _lib as L
+    from tests import test_kernels_gpu as K
+    x, tgt = O.synthetic_batch(8, 64, 128, seed=61)
+    x, tgt = x.cuda(), tgt.cuda()
+    res = []
+    try:
+        for split in (1, 4):
+            L.call("fea_set_persistent_split", split)
+            assert L.load().fea_get_persistent_split() == split
+            torch.manual_seed(23)
+            m = fea_amd.FloorPlanSegmentationModel(compute_dtype="bf16").cuda()
+            tr = UNetTrainer(m, dict(learning_rate=1e-3))
+            losses = [float(tr.step(x, tgt)) for _ in range(2)]
+            torch.cuda.synchronize()
+            res.append((losses, tr.eng.flat_grad.clone()))
+            if split == 4:
+                K.test_persistent_conv3x3_fwd_stats_dgrad_and_bnred((5, 64, 128, 64, 64))
+                K.test_persistent_conv3x3_fwd_stats_dgrad_and_bnred((2, 16, 96, 128, 256))
+                K.test_conv3x3_wgrad(torch.bfloat16, (2, 32, 32, 64, 64))
+    finally:
+        L.call("fea_set_persistent_split", 1)
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a - b) < 1e-4 * abs(a), (a, b)
+    assert rel_l2(res[1][1], res[0][1]) < 2e-2           # second step's gradients: bf16 path, weights differ by rounding after step 1
