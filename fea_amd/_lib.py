@@ -37,6 +37,8 @@ SIGNATURES = {
     "fea_conv3x3_first": (I, [P, P, P, P, I, P, I, I, I, I, I, I, P]),
     "fea_first_wgrad_ws_bytes": (Z, [I, I, I, I]),
     "fea_conv3x3_first_wgrad": (I, [P, I, P, P, P, Z, I, I, I, I, I, I, P]),
+    "fea_first_wgrad_bnbwd_rows": (I, [I, I, I, I]),
+    "fea_conv3x3_first_wgrad_bnbwd": (I, [P, I, P, I, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, P]),
     "fea_conv3x3": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
     "fea_conv3x3_dgrad_bnred": (I, [P, I, P, P, I, P, I, P, P, P, P, P, I, I, I, I, I, I, P]),
     "fea_pack_conv3x3_frag": (I, [P, P, I, I, I, I, P]),
@@ -72,6 +74,9 @@ SIGNATURES = {
     "fea_head_loss_supported": (I, [I, I, I]),
     "fea_head_loss_sums": (I, [P, I, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "fea_head_loss_bwd": (I, [P, I, P, P, P, P, P, P, I, P, F, I, I, I, I, I, I, P]),
+    "fea_head_loss_bn_supported": (I, [I, I, I, I, I]),
+    "fea_head_loss_sums_bn": (I, [P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "fea_head_loss_bwd_bn": (I, [P, I, P, P, P, P, P, P, P, P, I, P, F, I, I, I, I, I, I, P]),
     "fea_bce_dice_sums": (I, [P, P, P, P, I, I, L, P]),
     "fea_loss_blocks": (I, [I, I, L]),
     "fea_bce_dice_sums_static": (I, [P, P, P, I, I, L, P]),

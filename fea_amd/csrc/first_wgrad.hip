@@ -23,6 +23,11 @@ struct FirstWgradArgs {
     const __bf16* dy; const float* x; float* slab;
     int lddy, C, H, W, Cout;
     int tiles_x, tiles_y, ntiles, tiles_per_split;
+    // BN variant (fea_conv3x3_first_wgrad_bnbwd): `dy` is the gradient da of the activated tensor, the conv-output gradient
+    // is formed in LDS from it and the pre-BN tensor y (BatchNorm + ReLU backward apply, elementwise.hip bn_relu_bwd_kernel)
+    const __bf16* ybn; int ldy;
+    const float *sc, *sh, *mu, *is, *coef;
+    float* part;                       // [split][Cout][2]: slot 0 = sum of the conv-output gradient (conv bias gradient), slot 1 = 0
 };
 
 constexpr int FW_HALO = 10 * 34;                 // floats per channel
@@ -34,8 +39,10 @@ constexpr int FW_DY_BYTES = 256 * 128;
 // half-wave ({x..x+3} and {x+8..x+11}, same 32-byte channel block) land in distinct banks
 __device__ __forceinline__ int fw_swz(int x) { return ((x >> 1) & 1) | (((x >> 3) & 1) << 1); }
 
+template <bool BN, int NW>
 __device__ __forceinline__ void fw_issue(const FirstWgradArgs& g, int m0, int wave, int lane, int tile, char* sb,
                                          const int (&xdesc)[10], int nxi) {
+    constexpr int DYB = BN ? 2 * FW_DY_BYTES : FW_DY_BYTES;      // BN: [da tile][y tile][halo]
     int tt = tile;
     const int tile_x = tt % g.tiles_x; tt /= g.tiles_x;
     const int tile_y = tt % g.tiles_y;
@@ -45,23 +52,29 @@ __device__ __forceinline__ void fw_issue(const FirstWgradArgs& g, int m0, int wa
     const __bf16* dimg = g.dy + (long long)n_img * H * W * g.lddy + m0;
     const float* ximg = g.x + (long long)n_img * g.C * H * W;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int row = (it * 4 + wave) * 8 + (lane >> 3);
+    for (int it = 0; it < 32 / NW; ++it) {
+        const int row = (it * NW + wave) * 8 + (lane >> 3);
         const int ty = row >> 5, tx = row & 31;
         const int gy = y0 + ty, gx = x0 + tx;
         const int chunk = (lane & 7) ^ (fw_swz(tx) << 1);
         const __bf16* src = (gy < H && gx < W) ? dimg + (long long)(gy * W + gx) * g.lddy + chunk * 8
                                                : reinterpret_cast<const __bf16*>(fea_zero_line);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sb + (it * 4 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sb + (it * NW + wave) * 1024), 16, 0, 0);
+        if constexpr (BN) {
+            const __bf16* yimg = g.ybn + (long long)n_img * H * W * g.ldy + m0;
+            const __bf16* ysrc = (gy < H && gx < W) ? yimg + (long long)(gy * W + gx) * g.ldy + chunk * 8
+                                                    : reinterpret_cast<const __bf16*>(fea_zero_line);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)ysrc, (lds_void_t*)(sb + FW_DY_BYTES + (it * NW + wave) * 1024), 16, 0, 0);
+        }
     }
 #pragma unroll
-    for (int it = 0; it < 10; ++it) {
-        if (it * 4 + wave < nxi) {                       // wave-uniform
+    for (int it = 0; it < 40 / NW; ++it) {
+        if (it * NW + wave < nxi) {                      // wave-uniform
             const int d = xdesc[it];                      // c | hy << 8 | hx << 16 | invalid << 24
             const int c = d & 0xff, gy = y0 + ((d >> 8) & 0xff) - 1, gx = x0 + ((d >> 16) & 0xff) - 1;
             const bool ok = !(d >> 24) && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const float* src = ok ? ximg + ((long long)c * H + gy) * W + gx : reinterpret_cast<const float*>(fea_zero_line);
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sb + FW_DY_BYTES + (it * 4 + wave) * 256), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sb + DYB + (it * NW + wave) * 256), 4, 0, 0);
         }
     }
 }
@@ -69,16 +82,16 @@ __device__ __forceinline__ void fw_issue(const FirstWgradArgs& g, int m0, int wa
 // Multiply the tile resident in `rd` (rows ty = wave, wave + 4) while the LDS-DMA of the
 // next tile lands in `dma`.  __restrict__ on purpose: see wgrad2.hip (keeps hipcc from
 // draining vmcnt before every LDS read).
-template <int XB>
+template <int XB, bool BN, int NW>
 __device__ __forceinline__ void fw_step(const FirstWgradArgs& g, int m0, int wave, int lane, int next_tile,
                                         char* __restrict__ dma, const char* __restrict__ rd,
                                         const int (&xdesc)[10], int nxi, const int (&boff)[4], int NT, f32x4 (&acc)[4][4]) {
-    if (next_tile >= 0) fw_issue(g, m0, wave, lane, next_tile, dma, xdesc, nxi);
+    if constexpr (!BN) { if (next_tile >= 0) fw_issue<false, NW>(g, m0, wave, lane, next_tile, dma, xdesc, nxi); }
     const int r16 = lane & 15, q = lane >> 4;
-    const float* hal = reinterpret_cast<const float*>(rd + FW_DY_BYTES);
+    const float* hal = reinterpret_cast<const float*>(rd + (BN ? 2 * FW_DY_BYTES : FW_DY_BYTES));
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int ty = wave + 4 * kk;
+    for (int kk = 0; kk < 8 / NW; ++kk) {
+        const int ty = wave + NW * kk;
         // A: dy^T fragments of the four 16-channel M tiles, pixels 8q .. 8q+7 of row ty
         u32x4 af[4];
 #pragma unroll
@@ -108,10 +121,14 @@ __device__ __forceinline__ void fw_step(const FirstWgradArgs& g, int m0, int wav
     }
 }
 
-template <int XB>
-__global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstWgradArgs g) {
-    constexpr int FW_STAGE = FW_DY_BYTES + XB;
-    static_assert(2 * FW_STAGE >= 4 * 64 * 64 * 4, "the epilogue sums four 64 x 64 fp32 tiles through LDS");
+// BN: 8 waves (two per SIMD: the transform is ~800 dependent VALU operations per thread and tile, which one wave per SIMD does not
+// hide behind the next tile's loads), each takes one 32-pixel row of the tile as its MFMA k-step
+template <int XB, bool BN>
+__global__ __launch_bounds__(BN ? 512 : 256) void first_wgrad_kernel(const FirstWgradArgs g) {
+    constexpr int NW = BN ? 8 : 4, NT_ = NW * 64;
+    constexpr int FW_STAGE = (BN ? 2 : 1) * FW_DY_BYTES + XB;
+    static_assert(2 * FW_STAGE >= 4 * 64 * 64 * 4 + (BN ? NT_ * 8 * 4 : 0), "the epilogue sums 64 x 64 fp32 tiles through LDS");
+    static_assert(2 * FW_STAGE <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(128))) char smem[2 * FW_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
@@ -121,8 +138,8 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstWgradArgs g
 
     int xdesc[10];
 #pragma unroll
-    for (int it = 0; it < 10; ++it) {
-        const int e = (it * 4 + wave) * 64 + lane;
+    for (int it = 0; it < 40 / NW; ++it) {
+        const int e = (it * NW + wave) * 64 + lane;
         const int c = e / FW_HALO, rr = e - c * FW_HALO;
         const int hy = rr / 34, hx = rr - hy * 34;
         xdesc[it] = c | (hy << 8) | (hx << 16) | ((c >= C ? 1 : 0) << 24);
@@ -143,28 +160,106 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstWgradArgs g
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[m][nt][j] = 0.f;
 
+    // BN: this thread transforms the 16-byte pieces its own wave's LDS-DMA wrote: row (it*NW + wave)*8 + lane/8 of the tile,
+    // i.e. tile column tx = (wave*8 + lane/8) & 31 for every `it`, LDS slot lane & 7 = source chunk ^ swizzle(tx): always the
+    // same eight channels
+    const int txf = (wave * 8 + (lane >> 3)) & 31;
+    const int chunkf = (lane & 7) ^ (fw_swz(txf) << 1);
+    float sc[8], sh[8], mu[8], is[8], c1[8], c2[8], a0[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = m0 + chunkf * 8 + j;
+        sc[j] = BN ? g.sc[ch] : 0.f; sh[j] = BN ? g.sh[ch] : 0.f; mu[j] = BN ? g.mu[ch] : 0.f; is[j] = BN ? g.is[ch] : 0.f;
+        c1[j] = BN ? g.coef[2 * ch] : 0.f; c2[j] = BN ? g.coef[2 * ch + 1] : 0.f;
+        a0[j] = 0.f;
+    }
+    const bool partial = (g.H & 7) || (g.W & 31);
+
     const int t_begin = split * g.tiles_per_split;
     const int t_end = min(t_begin + g.tiles_per_split, g.ntiles);
-    if (t_begin < t_end) fw_issue(g, m0, wave, lane, t_begin, smem, xdesc, nxi);
+    if (t_begin < t_end) fw_issue<BN, NW>(g, m0, wave, lane, t_begin, smem, xdesc, nxi);
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int stage = (tile - t_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                 // tile landed; the other stage is free
-        fw_step<XB>(g, m0, wave, lane, tile + 1 < t_end ? tile + 1 : -1, smem + (stage ^ 1) * FW_STAGE, smem + stage * FW_STAGE,
-                xdesc, nxi, boff, NT, acc);
+        if constexpr (BN) {
+            char* sb = smem + stage * FW_STAGE;
+            // the next tile's loads go first: they are in flight during the transform and the multiplication of this one
+            if (tile + 1 < t_end) fw_issue<true, NW>(g, m0, wave, lane, tile + 1, smem + (stage ^ 1) * FW_STAGE, xdesc, nxi);
+            int y0 = 0, x0 = 0;
+            if (partial) {
+                int tt = tile;
+                x0 = (tt % g.tiles_x) * 32; tt /= g.tiles_x;
+                y0 = (tt % g.tiles_y) * 8;
+            }
+#pragma unroll
+            for (int it = 0; it < 32 / NW; ++it) {
+                char* p = sb + (it * NW + wave) * 1024 + lane * 16;
+                const bf16x8 gv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+                const bf16x8 yv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + FW_DY_BYTES));
+                const int row = (it * NW + wave) * 8 + (lane >> 3);
+                const bool ok = !partial || (y0 + (row >> 5) < g.H && x0 + (row & 31) < g.W);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // BatchNorm + ReLU backward, as bn_relu_bwd_kernel<T, false, true> (elementwise.hip) forms it
+                    const float yf = (float)yv[j], gf = (float)gv[j];
+                    const float act = fmaxf(__builtin_fmaf(yf, sc[j], sh[j]), 0.f);
+                    const float gg = act > 0.f ? gf : 0.f;
+                    const float xh = (yf - mu[j]) * is[j];
+                    float d = sc[j] * (gg - c1[j] - xh * c2[j]);
+                    d = ok ? d : 0.f;
+                    o[j] = (__bf16)d; a0[j] += d;
+                }
+                *reinterpret_cast<u32x4*>(p) = __builtin_bit_cast(u32x4, o);
+            }
+            __syncthreads();             // every wave's rows hold the conv-output gradient
+        }
+        fw_step<XB, BN, NW>(g, m0, wave, lane, tile + 1 < t_end ? tile + 1 : -1, smem + (stage ^ 1) * FW_STAGE, smem + stage * FW_STAGE,
+                        xdesc, nxi, boff, NT, acc);
     }
     __syncthreads();
-    // sum the four waves: [wave][64 co][64 n] fp32 in LDS (64 KB)
+    // sum the waves: [wave % 4][64 co][64 n] fp32 in LDS (64 KB); with 8 waves the second four add into the first four's slots
     float* ot = reinterpret_cast<float*>(smem);
+    if (wave < 4) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ot[(wave * 64 + m * 16 + 4 * q + j) * 64 + nt * 16 + r16] = acc[m][nt][j];
+                for (int j = 0; j < 4; ++j) ot[(wave * 64 + m * 16 + 4 * q + j) * 64 + nt * 16 + r16] = acc[m][nt][j];
+    }
+    float* cb = ot + 4 * 64 * 64;                          // BN: [thread][8] channel sums
+    if constexpr (BN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cb[tid * 8 + j] = a0[j];
+        __syncthreads();
+        if (wave >= 4) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ot[((wave - 4) * 64 + m * 16 + 4 * q + j) * 64 + nt * 16 + r16] += acc[m][nt][j];
+        }
+    }
     __syncthreads();
     float* dst = g.slab + ((long long)split * g.Cout + m0) * 64;
-    for (int i = tid; i < 64 * 64; i += 256) dst[i] = (ot[i] + ot[4096 + i]) + (ot[8192 + i] + ot[12288 + i]);
+    for (int i = tid; i < 64 * 64; i += NT_) dst[i] = (ot[i] + ot[4096 + i]) + (ot[8192 + i] + ot[12288 + i]);
+    if constexpr (BN) {
+        if (tid < 64) {
+            // channel tid = chunk cc, element j: held by one thread of every (wave, lane / 8) pair; summed in a fixed order
+            const int cc = tid >> 3, j = tid & 7;
+            float s = 0.f;
+            for (int w_ = 0; w_ < NW; ++w_)
+                for (int r = 0; r < 8; ++r) {
+                    const int l7 = cc ^ (fw_swz((w_ * 8 + r) & 31) << 1);
+                    s += cb[(w_ * 64 + r * 8 + l7) * 8 + j];
+                }
+            float* pd = g.part + ((long long)split * g.Cout + m0 + tid) * 2;
+            pd[0] = s; pd[1] = 0.f;
+        }
+    }
 }
 
 // out[co][c][tap] = sum over splits of slab[split][co][tap*C + c]
@@ -192,11 +287,11 @@ __global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __
 }
 
 struct FwPlan { int tiles_x, tiles_y, ntiles, splits, tiles_per_split; };
-static FwPlan fw_plan(int N, int H, int W, int Cout) {
+static FwPlan fw_plan(int N, int H, int W, int Cout, int per_cu = 2) {
     FwPlan p;
     p.tiles_x = (W + 31) / 32; p.tiles_y = (H + 7) / 8;
     p.ntiles = N * p.tiles_x * p.tiles_y;
-    int want = 512 / (Cout / 64);
+    int want = 256 * per_cu / (Cout / 64);
     if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
     p.tiles_per_split = (p.ntiles + want - 1) / want;
@@ -226,8 +321,47 @@ extern "C" int fea_conv3x3_first_wgrad(const void* dy, int lddy, const float* x,
     a.dy = (const __bf16*)dy; a.x = x; a.slab = (float*)ws; a.lddy = lddy; a.C = C; a.H = H; a.W = W; a.Cout = Cout;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
     hipStream_t s = (hipStream_t)stream;
-    if (C <= 3) hipLaunchKernelGGL(first_wgrad_kernel<4096>, dim3((unsigned)p.splits, (unsigned)(Cout / 64)), dim3(256), 0, s, a);
-    else        hipLaunchKernelGGL(first_wgrad_kernel<10240>, dim3((unsigned)p.splits, (unsigned)(Cout / 64)), dim3(256), 0, s, a);
+    if (C <= 3) hipLaunchKernelGGL((first_wgrad_kernel<4096, false>), dim3((unsigned)p.splits, (unsigned)(Cout / 64)), dim3(256), 0, s, a);
+    else        hipLaunchKernelGGL((first_wgrad_kernel<10240, false>), dim3((unsigned)p.splits, (unsigned)(Cout / 64)), dim3(256), 0, s, a);
+    FEA_LAUNCH_CHECK();
+    const int total = Cout * 9 * C;
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s,
+                       (const float*)ws, dW, p.splits, Cout, C);
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+
+// rows of `part` that fea_conv3x3_first_wgrad_bnbwd writes (one per pixel split)
+extern "C" int fea_first_wgrad_bnbwd_rows(int N, int H, int W, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 64) return 0;
+    return fw_plan(N, H, W, Cout, 1).splits;
+}
+
+// BatchNorm + ReLU backward of enc1[1..2] fused into the first layer's weight gradient: the conv-output gradient
+// dy = scale * (g - c1 - xhat * c2), g = da * [relu(bn(y)) > 0] (what fea_bn_relu_bwd_apply writes) is formed in LDS from da and
+// y and never goes to HBM -- the first layer has no data gradient, so the weight gradient is dy's only reader.
+extern "C" int fea_conv3x3_first_wgrad_bnbwd(const void* da, int ldda, const void* y, int ldy, const float* scale, const float* shift,
+                                             const float* save_mean, const float* save_invstd, const float* coef,
+                                             const float* x, float* dW, float* part, void* ws, size_t ws_bytes,
+                                             int N, int C, int H, int W, int Cout, int dtype, void* stream) {
+    const char* who = "fea_conv3x3_first_wgrad_bnbwd";
+    FEA_CHECK(dtype == FEA_BF16, FEA_E_UNSUPPORTED_SHAPE, "%s: bf16 only", who);
+    FEA_CHECK(da && y && scale && shift && save_mean && save_invstd && coef && x && dW && part && ws, FEA_E_BADARG, "%s: null pointer", who);
+    FEA_CHECK(N > 0 && H > 0 && W > 0 && C > 0 && 9 * C <= 64, FEA_E_UNSUPPORTED_SHAPE, "%s: N=%d H=%d W=%d C=%d", who, N, H, W, C);
+    FEA_CHECK(Cout > 0 && Cout % 64 == 0 && ldda >= Cout && ldda % 8 == 0 && ldy >= Cout && ldy % 8 == 0 &&
+              ((uintptr_t)da % 16 == 0) && ((uintptr_t)y % 16 == 0), FEA_E_BADARG, "%s: Cout=%d ldda=%d ldy=%d", who, Cout, ldda, ldy);
+    FEA_CHECK((long long)H * W * ldda < (1ll << 31) && (long long)H * W * ldy < (1ll << 31) && (long long)C * H * W < (1ll << 31),
+              FEA_E_UNSUPPORTED_SHAPE, "%s: image too large", who);
+    FwPlan p = fw_plan(N, H, W, Cout, 1);
+    const size_t need = (size_t)p.splits * Cout * 64 * sizeof(float);
+    FEA_CHECK(ws_bytes >= need, FEA_E_WORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
+    FirstWgradArgs a{};
+    a.dy = (const __bf16*)da; a.x = x; a.slab = (float*)ws; a.lddy = ldda; a.C = C; a.H = H; a.W = W; a.Cout = Cout;
+    a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
+    a.ybn = (const __bf16*)y; a.ldy = ldy; a.sc = scale; a.sh = shift; a.mu = save_mean; a.is = save_invstd; a.coef = coef; a.part = part;
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 3) hipLaunchKernelGGL((first_wgrad_kernel<4096, true>), dim3((unsigned)p.splits, (unsigned)(Cout / 64)), dim3(512), 0, s, a);
+    else        hipLaunchKernelGGL((first_wgrad_kernel<10240, true>), dim3((unsigned)p.splits, (unsigned)(Cout / 64)), dim3(512), 0, s, a);
     FEA_LAUNCH_CHECK();
     const int total = Cout * 9 * C;
     hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s,

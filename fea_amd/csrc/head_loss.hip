@@ -727,15 +727,44 @@ __device__ __forceinline__ void loss_terms_fast(float v, float tt, float& sb, fl
 #ifndef HL_SUMS_NT
 #define HL_SUMS_NT 0              // plain loads: 0.49 ms against 0.58 with nontemporal ones (the activation was written by the kernel before and is read again by the backward kernel)
 #endif
-template <int NE>                                  // accumulator registers that hold classes: (classes + 3) / 4
+// BNA: `a` is the PRE-BatchNorm output of dec1.3 and the activation relu(a * scale + shift), rounded to bf16 as fea_bn_relu_pool
+// would have stored it, is formed in registers after the load: the activated tensor is never written (fea_head_loss_*_bn)
+struct HlBn { float sc[16], sh[16]; };
+template <bool BNA>
+__device__ __forceinline__ void hl_bn_load(HlBn& b, const float* __restrict__ sc, const float* __restrict__ sh, int q) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int ch = (j >> 3) * 32 + q * 8 + (j & 7);        // x0: channels 8q .. 8q+7, x1: 32 + 8q ..
+        b.sc[j] = BNA ? sc[ch] : 0.f; b.sh[j] = BNA ? sh[ch] : 0.f;
+    }
+}
+template <bool BNA>
+__device__ __forceinline__ void hl_bn_act(const HlBn& b, u32x4& x0, u32x4& x1) {
+    if constexpr (BNA) {
+        const bf16x8 y0 = __builtin_bit_cast(bf16x8, x0), y1 = __builtin_bit_cast(bf16x8, x1);
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = fmaxf(__builtin_fmaf((float)y0[j], b.sc[j], b.sh[j]), 0.f);
+            v[8 + j] = fmaxf(__builtin_fmaf((float)y1[j], b.sc[8 + j], b.sh[8 + j]), 0.f);
+        }
+        x0 = u32x4{hl_pack(v[0], v[1]), hl_pack(v[2], v[3]), hl_pack(v[4], v[5]), hl_pack(v[6], v[7])};
+        x1 = u32x4{hl_pack(v[8], v[9]), hl_pack(v[10], v[11]), hl_pack(v[12], v[13]), hl_pack(v[14], v[15])};
+    }
+}
+
+template <int NE, bool BNA>                        // accumulator registers that hold classes: (classes + 3) / 4
 __global__ __launch_bounds__(256) void head_loss_sums_mfma_kernel(const __bf16* __restrict__ a, int lda, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, const uint8_t* __restrict__ tgt,
                                                                   float* __restrict__ logits, float* __restrict__ part,
-                                                                  int ntile, int HW, int Ccls) {
+                                                                  int ntile, int HW, int Ccls,
+                                                                  const float* __restrict__ bn_sc, const float* __restrict__ bn_sh) {
     __shared__ float red[4][8][4];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r16 = lane & 15, q = lane >> 4;
     HlFrag f;
     hl_weights(f, w, bias, Ccls, r16, q);
+    HlBn bn;
+    hl_bn_load<BNA>(bn, bn_sc, bn_sh, q);
     float sb[NE], si[NE], sp[NE], st[NE];
     int lc[NE];                                    // target byte of (class, pixel) relative to (image, hw); absent classes read class q
 #pragma unroll
@@ -762,7 +791,9 @@ __global__ __launch_bounds__(256) void head_loss_sums_mfma_kernel(const __bf16* 
         xa += xstep; ahead.next(HW);                  // (past the end neither is dereferenced)
     };
     auto tile = [&](const HlTile<NE>& c) {
-        const f32x4 v = hl_logits(f, c.x0, c.x1);
+        u32x4 x0 = c.x0, x1 = c.x1;
+        hl_bn_act<BNA>(bn, x0, x1);
+        const f32x4 v = hl_logits(f, x0, x1);
         if (logits) {                                                  // (uniform)
             float* lp = logits + ((long long)cur.n * CHW + cur.hw);
 #pragma unroll
@@ -813,12 +844,13 @@ __global__ __launch_bounds__(256) void head_loss_sums_mfma_kernel(const __bf16* 
 #ifndef HL_BWD_AHEAD
 #define HL_BWD_AHEAD 1            // 2 measured the same (0.96 vs 0.95 ms at batch 64 @512^2): the kernel is not waiting for HBM latency
 #endif
-template <int NC, int D>                           // classes the dW accumulators are sized for (4, 6 or 8); tiles of read-ahead
+template <int NC, int D, bool BNA>                 // classes the dW accumulators are sized for (4, 6 or 8); tiles of read-ahead
 __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16* __restrict__ a, int lda, const float* __restrict__ w,
                                                                     const float* __restrict__ bias, const uint8_t* __restrict__ tgt,
                                                                     const double* __restrict__ sums, float* __restrict__ loss,
                                                                     __bf16* __restrict__ da, int ldda, float* __restrict__ part,
-                                                                    float gscale, int ntile, int HW, int N, int Ccls) {
+                                                                    float gscale, int ntile, int HW, int N, int Ccls,
+                                                                    const float* __restrict__ bn_sc, const float* __restrict__ bn_sh) {
     constexpr int NE = (NC + 3) / 4;
     __shared__ float red[4][NC * 65];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r16 = lane & 15, q = lane >> 4;
@@ -833,6 +865,8 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
     }
     HlFrag f;
     hl_weights(f, w, bias, Ccls, r16, q);
+    HlBn bn;
+    hl_bn_load<BNA>(bn, bn_sc, bn_sh, q);
     // GEMM 2 A operand, row block mb: lane (row = lane % 16, q): k-slot j < 4 <-> class q + 4j, slots 4..7 zero.  Row i of
     // block mb is channel 32 (mb / 2) + 8 (i / 4) + 4 (mb % 2) + i % 4: the accumulators of a lane over a block pair are
     // eight consecutive channels.
@@ -886,7 +920,9 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
         xa += xstep; ahead.next(HW);                  // (past the end neither is dereferenced)
     };
     auto tile = [&](const HlTile<NE>& c) {
-        const f32x4 v = hl_logits(f, c.x0, c.x1);
+        u32x4 x0 = c.x0, x1 = c.x1;
+        hl_bn_act<BNA>(bn, x0, x1);
+        const f32x4 v = hl_logits(f, x0, x1);
         float d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
@@ -920,7 +956,7 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
         // dW: the dlogits of this lane's pixel for every class (lane (pixel, c % 4) holds class c in register c / 4) x its 16 channels
         float xf[16];
         {
-            const bf16x8 b0 = __builtin_bit_cast(bf16x8, c.x0), b1 = __builtin_bit_cast(bf16x8, c.x1);
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, x0), b1 = __builtin_bit_cast(bf16x8, x1);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { xf[j] = (float)b0[j]; xf[8 + j] = (float)b1[j]; }
         }
@@ -1053,10 +1089,9 @@ extern "C" int fea_binarise(const uint8_t* grey, uint8_t* out, long long n, void
 // ---- fused head + loss ---------------------------------------------------------------------
 extern "C" int fea_head_loss_supported(int H, int W, int Ccls) { return ((long long)H * W) % 4 == 0 && Ccls >= 1 && Ccls <= 8; }
 
-extern "C" int fea_head_loss_sums(const void* a, int lda, const float* w, const float* bias, const uint8_t* target,
-                                  float* logits, double* sums, float* part, int N, int H, int W, int Cin, int Ccls,
-                                  int dtype, void* stream) {
-    const char* who = "fea_head_loss_sums";
+static int head_loss_sums_impl(const char* who, const void* a, int lda, const float* bn_sc, const float* bn_sh, const float* w, const float* bias,
+                               const uint8_t* target, float* logits, double* sums, float* part, int N, int H, int W, int Cin, int Ccls,
+                               int dtype, void* stream) {
     FEA_CHECK(a && w && bias && target && sums && part && N > 0 && H > 0 && W > 0, FEA_E_BADARG, "%s: bad args", who);
     FEA_CHECK(Cin == 64 && lda >= 64 && lda % 8 == 0, FEA_E_UNSUPPORTED_SHAPE, "%s: Cin=%d lda=%d", who, Cin, lda);
     FEA_CHECK(fea_head_loss_supported(H, W, Ccls), FEA_E_UNSUPPORTED_SHAPE, "%s: needs H*W %% 4 == 0 and 1..8 classes (use fea_head_fwd + fea_bce_dice_sums)", who);
@@ -1065,8 +1100,11 @@ extern "C" int fea_head_loss_sums(const void* a, int lda, const float* w, const 
     const int nblk = head_blocks(npix);
     hipStream_t s = (hipStream_t)stream;
     const bool mfma = dtype == FEA_BF16 && HW % 16 == 0 && npix * Ccls < (1ll << 31);       // 32-bit tile positions and target offsets
-    if (mfma && Ccls <= 4) hipLaunchKernelGGL(head_loss_sums_mfma_kernel<1>, dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, logits, part, (int)(npix / 16), (int)HW, Ccls);
-    else if (mfma) hipLaunchKernelGGL(head_loss_sums_mfma_kernel<2>, dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, logits, part, (int)(npix / 16), (int)HW, Ccls);
+    FEA_CHECK(!bn_sc || (mfma && bn_sh), FEA_E_UNSUPPORTED_SHAPE, "%s: the fused BatchNorm + ReLU needs bf16 and H*W %% 16 == 0", who);
+#define HLS_LAUNCH(NEV, BNV) hipLaunchKernelGGL((head_loss_sums_mfma_kernel<NEV, BNV>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, logits, part, (int)(npix / 16), (int)HW, Ccls, bn_sc, bn_sh)
+    if (mfma && Ccls <= 4) { if (bn_sc) HLS_LAUNCH(1, true); else HLS_LAUNCH(1, false); }
+    else if (mfma) { if (bn_sc) HLS_LAUNCH(2, true); else HLS_LAUNCH(2, false); }
+#undef HLS_LAUNCH
     else if (dtype == FEA_BF16) hipLaunchKernelGGL((head_loss_sums_kernel<__bf16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, logits, part, npix / 4, HW, Ccls);
     else if (dtype == FEA_F32) hipLaunchKernelGGL((head_loss_sums_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)a, lda, w, bias, target, logits, part, npix / 4, HW, Ccls);
     else { fea_set_error("%s: bad dtype", who); return FEA_E_BADARG; }
@@ -1077,10 +1115,26 @@ extern "C" int fea_head_loss_sums(const void* a, int lda, const float* w, const 
     return FEA_OK;
 }
 
-extern "C" int fea_head_loss_bwd(const void* a, int lda, const float* w, const float* bias, const uint8_t* target,
-                                 const double* sums, float* loss, void* da, int ldda, float* part, float gscale,
-                                 int N, int H, int W, int Cin, int Ccls, int dtype, void* stream) {
-    const char* who = "fea_head_loss_bwd";
+extern "C" int fea_head_loss_sums(const void* a, int lda, const float* w, const float* bias, const uint8_t* target,
+                                  float* logits, double* sums, float* part, int N, int H, int W, int Cin, int Ccls,
+                                  int dtype, void* stream) {
+    return head_loss_sums_impl("fea_head_loss_sums", a, lda, nullptr, nullptr, w, bias, target, logits, sums, part, N, H, W, Cin, Ccls, dtype, stream);
+}
+// 1 when fea_head_loss_sums_bn / fea_head_loss_bwd_bn serve this problem (the matrix-pipe form of the fused head + loss kernels)
+extern "C" int fea_head_loss_bn_supported(int N, int H, int W, int Ccls, int dtype) {
+    const long long HW = (long long)H * W;
+    return dtype == FEA_BF16 && N > 0 && fea_head_loss_supported(H, W, Ccls) && Ccls <= 6 && HW % 16 == 0 && (long long)N * HW * Ccls < (1ll << 31);
+}
+extern "C" int fea_head_loss_sums_bn(const void* y, int ldy, const float* bn_scale, const float* bn_shift, const float* w, const float* bias,
+                                     const uint8_t* target, float* logits, double* sums, float* part, int N, int H, int W, int Cin,
+                                     int Ccls, int dtype, void* stream) {
+    FEA_CHECK(bn_scale && bn_shift, FEA_E_BADARG, "fea_head_loss_sums_bn: null coefficients");
+    return head_loss_sums_impl("fea_head_loss_sums_bn", y, ldy, bn_scale, bn_shift, w, bias, target, logits, sums, part, N, H, W, Cin, Ccls, dtype, stream);
+}
+
+static int head_loss_bwd_impl(const char* who, const void* a, int lda, const float* bn_sc, const float* bn_sh, const float* w, const float* bias,
+                              const uint8_t* target, const double* sums, float* loss, void* da, int ldda, float* part, float gscale,
+                              int N, int H, int W, int Cin, int Ccls, int dtype, void* stream) {
     FEA_CHECK(a && w && bias && target && sums && da && part && N > 0 && H > 0 && W > 0, FEA_E_BADARG, "%s: bad args", who);
     FEA_CHECK(Cin == 64 && lda >= 64 && lda % 8 == 0 && ldda >= 64 && ldda % 8 == 0, FEA_E_UNSUPPORTED_SHAPE, "%s: Cin=%d lda=%d ldda=%d", who, Cin, lda, ldda);
     FEA_CHECK(fea_head_loss_supported(H, W, Ccls), FEA_E_UNSUPPORTED_SHAPE, "%s: needs H*W %% 4 == 0 and 1..8 classes", who);
@@ -1091,12 +1145,31 @@ extern "C" int fea_head_loss_bwd(const void* a, int lda, const float* w, const f
     ppb = (ppb + 63) / 64 * 64;
     hipStream_t s = (hipStream_t)stream;
     const bool mfma = dtype == FEA_BF16 && HW % 16 == 0 && npix * Ccls < (1ll << 31);       // as in fea_head_loss_sums
-    if (mfma && Ccls <= 4) hipLaunchKernelGGL((head_loss_bwd_mfma_kernel<4, HL_BWD_AHEAD>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, (int)(npix / 16), (int)HW, N, Ccls);
-    else if (mfma && Ccls <= 6) hipLaunchKernelGGL((head_loss_bwd_mfma_kernel<6, HL_BWD_AHEAD>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, (int)(npix / 16), (int)HW, N, Ccls);
-    else if (mfma) hipLaunchKernelGGL((head_loss_bwd_mfma_kernel<8, 1>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, (int)(npix / 16), (int)HW, N, Ccls);
+    FEA_CHECK(!bn_sc || (mfma && bn_sh), FEA_E_UNSUPPORTED_SHAPE, "%s: the fused BatchNorm + ReLU needs bf16 and H*W %% 16 == 0", who);
+#define HLB_LAUNCH(NCV, DV, BNV) hipLaunchKernelGGL((head_loss_bwd_mfma_kernel<NCV, DV, BNV>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, (int)(npix / 16), (int)HW, N, Ccls, bn_sc, bn_sh)
+    if (mfma && Ccls <= 4) { if (bn_sc) HLB_LAUNCH(4, HL_BWD_AHEAD, true); else HLB_LAUNCH(4, HL_BWD_AHEAD, false); }
+    else if (mfma && Ccls <= 6) { if (bn_sc) HLB_LAUNCH(6, HL_BWD_AHEAD, true); else HLB_LAUNCH(6, HL_BWD_AHEAD, false); }
+    else if (mfma) {
+        // (7-8 classes with the fused BatchNorm: the 128 dW accumulators + 32 coefficients do not fit two waves per SIMD)
+        FEA_CHECK(!bn_sc, FEA_E_UNSUPPORTED_SHAPE, "%s: the fused BatchNorm + ReLU serves up to 6 classes", who);
+        HLB_LAUNCH(8, 1, false);
+    }
+#undef HLB_LAUNCH
     else if (dtype == FEA_BF16) hipLaunchKernelGGL((head_loss_bwd_kernel<__bf16>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, npix, HW, N, Ccls, ppb);
     else if (dtype == FEA_F32) hipLaunchKernelGGL((head_loss_bwd_kernel<float>), dim3(nblk), dim3(256), 0, s, (const float*)a, lda, w, bias, target, sums, loss, (float*)da, ldda, part, gscale, npix, HW, N, Ccls, ppb);
     else { fea_set_error("%s: bad dtype", who); return FEA_E_BADARG; }
     FEA_LAUNCH_CHECK();
     return FEA_OK;
+}
+
+extern "C" int fea_head_loss_bwd(const void* a, int lda, const float* w, const float* bias, const uint8_t* target,
+                                 const double* sums, float* loss, void* da, int ldda, float* part, float gscale,
+                                 int N, int H, int W, int Cin, int Ccls, int dtype, void* stream) {
+    return head_loss_bwd_impl("fea_head_loss_bwd", a, lda, nullptr, nullptr, w, bias, target, sums, loss, da, ldda, part, gscale, N, H, W, Cin, Ccls, dtype, stream);
+}
+extern "C" int fea_head_loss_bwd_bn(const void* y, int ldy, const float* bn_scale, const float* bn_shift, const float* w, const float* bias,
+                                    const uint8_t* target, const double* sums, float* loss, void* da, int ldda, float* part, float gscale,
+                                    int N, int H, int W, int Cin, int Ccls, int dtype, void* stream) {
+    FEA_CHECK(bn_scale && bn_shift, FEA_E_BADARG, "fea_head_loss_bwd_bn: null coefficients");
+    return head_loss_bwd_impl("fea_head_loss_bwd_bn", y, ldy, bn_scale, bn_shift, w, bias, target, sums, loss, da, ldda, part, gscale, N, H, W, Cin, Ccls, dtype, stream);
 }

@@ -513,6 +513,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
             __syncthreads();                       // previous chunk fully consumed
             ISTAMP(0);
             stage_W(ch * 9, 0);
+#ifdef IG_EXP_NO_STAGE_A
+            if (ch == 0)       // EXPERIMENT (wrong results): no halo staging after the first chunk = upper bound of what hiding it could gain
+#endif
             stage_A(ch, 0);
             ISTAMP(1);
             __syncthreads();                       // (drains the LDS-DMA: vmcnt(0) before the barrier)

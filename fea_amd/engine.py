@@ -244,6 +244,10 @@ class UNetEngine:
         # work-split factor of the persistent kernels (fea_set_persistent_split): FEA_AMD_PERSISTENT_SPLIT overrides the library default
         if os.environ.get("FEA_AMD_PERSISTENT_SPLIT"):
             L.call("fea_set_persistent_split", int(os.environ["FEA_AMD_PERSISTENT_SPLIT"]))
+        # dec1.3: BatchNorm + ReLU applied inside the fused head + loss kernels' loaders (FEA_AMD_FUSE_HEAD_BN=0: separate pass)
+        self.fuse_head_bn = os.environ.get("FEA_AMD_FUSE_HEAD_BN", "1") != "0"
+        # enc1.0: BatchNorm backward apply fused into the first layer's weight gradient (FEA_AMD_FUSE_FIRST_WGRAD=0: separate kernels)
+        self.fuse_first_wgrad = os.environ.get("FEA_AMD_FUSE_FIRST_WGRAD", "1") != "0"
         self.backward_count = 0        # backward passes run so far (ClipAdamW checks that it steps on one backward's gradients)
         L.load()
 
@@ -478,6 +482,9 @@ class UNetEngine:
         taps = self.debug_taps
 
         pl.x_in = x
+        # training step with the fused head + loss kernels: dec1.3's activated tensor is never written
+        pl.head_bn = bool(training and not head and taps is None and self.fuse_head_bn
+                          and L.call("fea_head_loss_bn_supported", N, H, W, self.num_classes, code))
         fold = (not training) and self.fold_bn and self.dtype == torch.bfloat16 and taps is None
         # Training: the ~40 weight re-packs of the step (forward + data-gradient layouts, 0.4 ms of
         # small launches) run on the second stream beside the first layer instead of in front of
@@ -554,6 +561,8 @@ class UNetEngine:
             else:
                 L.call("fea_bn_eval_coeffs", P[bn + ".weight"], P[bn + ".bias"], B[bn + ".running_mean"],
                        B[bn + ".running_var"], BN_EPS, cf["scale"], cf["shift"], cout, S)
+            if name == "dec1.3" and pl.head_bn:
+                return          # the fused head + loss kernels apply BatchNorm + ReLU in their loaders (fea_head_loss_*_bn)
             L.call("fea_bn_relu_pool", y, cf["scale"], cf["shift"], out_full, ld_full, out_pool, N, h, w, cout, code, S)
 
         es = torch.empty(0, dtype=self.dtype).element_size()
@@ -668,15 +677,16 @@ class UNetEngine:
             """Enqueue a weight-gradient kernel (second stream when overlapping) and report
             `names` ready behind it.  Everything enqueued on the main stream so far (the dY it
             reads, the bias / BatchNorm gradients in `names`) is ordered before it."""
+            run = fn if callable(fn) else (lambda *a: L.call(fn, *a))
             if side is None:
-                L.call(fn, *args_before_stream, S)
+                run(*args_before_stream, S)
                 done(*names)
                 return
             ev = torch.cuda.Event()
             ev.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ev)
-                L.call(fn, *args_before_stream, side.cuda_stream)
+                run(*args_before_stream, side.cuda_stream)
                 if reads_dY:
                     fe = torch.cuda.Event()
                     fe.record(side)
@@ -720,6 +730,7 @@ class UNetEngine:
                 wgrad("fea_conv3x3_wgrad", (dy3, c, pl.a0[blk], c, g[n3 + ".weight"], pl.ws, pl.ws_bytes, N, h, w, c, c, code),
                       (n3 + ".weight", n3 + ".bias", f"{blk}.4.weight", f"{blk}.4.bias"))
 
+            fuse_first = fuse and blk == "enc1" and self.first_direct and self.fuse_first_wgrad
             if fuse:
                 cf0 = pl.coef[n0]
                 rows_p = pm[n3][1]
@@ -727,6 +738,22 @@ class UNetEngine:
                        self._w_dgrad(n3, frag=rows_p > 0), pl.gmid, c, pl.y[n0], c,
                        cf0["scale"], cf0["shift"], cf0["mean"], cf0["invstd"], pl.part, N, h, w, c, c, code, S)
                 wg3()
+                if fuse_first:
+                    # enc1.0 has no data gradient: its BatchNorm backward apply runs inside its weight gradient's loader
+                    # (the conv-output gradient, 2 GB at batch 64 x 512^2, is neither written nor read back)
+                    bn1 = f"{blk}.1"
+                    L.call("fea_bn_bwd_finalize", pl.part, rows_p or L.call("fea_conv_num_tiles", N, h, w), N * h * w, P[bn1 + ".weight"],
+                           cf0["invstd"], g[bn1 + ".weight"], g[bn1 + ".bias"], pl.bncoef, c, S)
+                    rows1 = L.call("fea_first_wgrad_bnbwd_rows", N, h, w, c)
+
+                    def fused_first(_a, stream):
+                        # (one unit for the weight-gradient stream: the workspace and `part` are shared with the other weight gradients)
+                        L.call("fea_conv3x3_first_wgrad_bnbwd", pl.gmid, c, pl.y[n0], c, cf0["scale"], cf0["shift"], cf0["mean"],
+                               cf0["invstd"], pl.bncoef, pl.x_in, g[n0 + ".weight"], pl.part, pl.ws, pl.ws_bytes,
+                               N, self.in_channels, h, w, c, code, stream)
+                        L.call("fea_reduce_partials", pl.part, rows1, c, 0, g[n0 + ".bias"], stream)
+                    wgrad(fused_first, (None,), (n0 + ".weight", n0 + ".bias", f"{blk}.1.weight", f"{blk}.1.bias"), reads_dY=False)
+                    return
                 bn_bwd(n0, pl.gmid, c, None, h, w, c, reduced_tiles=rows_p or L.call("fea_conv_num_tiles", N, h, w))
             else:
                 L.call("fea_conv3x3", ring["dY"], c, self._w_dgrad(n3), None, pl.gmid, c, None, N, h, w, c, c, code, S)
@@ -756,11 +783,23 @@ class UNetEngine:
                 pl.loss_sums = torch.empty((self.num_classes, 4), dtype=torch.float64, device=self.device)
                 pl.loss_part = torch.empty(nblk * self.num_classes * 4, dtype=torch.float32, device=self.device)
                 pl.loss = torch.empty(1, dtype=torch.float32, device=self.device)
-            L.call("fea_head_loss_sums", pl.a3["dec1"], 64, P["out.weight"], P["out.bias"], tg, None, pl.loss_sums, pl.loss_part,
-                   N, H, W, 64, self.num_classes, code, S)
-            L.call("fea_head_loss_bwd", pl.a3["dec1"], 64, P["out.weight"], P["out.bias"], tg, pl.loss_sums, pl.loss,
-                   pl.G[0], 64, pl.head_part, 1.0, N, H, W, 64, self.num_classes, code, S)
+            if getattr(pl, "head_bn", False):
+                cfh = pl.coef["dec1.3"]
+                L.call("fea_head_loss_sums_bn", pl.y["dec1.3"], 64, cfh["scale"], cfh["shift"], P["out.weight"], P["out.bias"], tg, None,
+                       pl.loss_sums, pl.loss_part, N, H, W, 64, self.num_classes, code, S)
+                L.call("fea_head_loss_bwd_bn", pl.y["dec1.3"], 64, cfh["scale"], cfh["shift"], P["out.weight"], P["out.bias"], tg,
+                       pl.loss_sums, pl.loss, pl.G[0], 64, pl.head_part, 1.0, N, H, W, 64, self.num_classes, code, S)
+            else:
+                L.call("fea_head_loss_sums", pl.a3["dec1"], 64, P["out.weight"], P["out.bias"], tg, None, pl.loss_sums, pl.loss_part,
+                       N, H, W, 64, self.num_classes, code, S)
+                L.call("fea_head_loss_bwd", pl.a3["dec1"], 64, P["out.weight"], P["out.bias"], tg, pl.loss_sums, pl.loss,
+                       pl.G[0], 64, pl.head_part, 1.0, N, H, W, 64, self.num_classes, code, S)
         else:
+            if getattr(pl, "head_bn", False):
+                # the forward left dec1.3's activated tensor to the fused head + loss kernels, but the caller brings its own dlogits
+                cfh = pl.coef["dec1.3"]
+                L.call("fea_bn_relu_pool", pl.y["dec1.3"], cfh["scale"], cfh["shift"], pl.a3["dec1"], 64, None, N, H, W, 64, code, S)
+                pl.head_bn = False
             L.call("fea_head_bwd", dl, pl.a3["dec1"], 64, P["out.weight"], pl.G[0], 64, pl.head_part, N, H, W, 64, self.num_classes, code, S)
         L.call("fea_head_bwd_finalize", pl.head_part, nblk, g["out.weight"], g["out.bias"], 64, self.num_classes, S)
         done("out.weight", "out.bias")

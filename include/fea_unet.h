@@ -106,6 +106,16 @@ int fea_conv3x3_first(const float* x_nchw, const void* w_packed, const float* bi
 size_t fea_first_wgrad_ws_bytes(int N, int H, int W, int Cout);
 int fea_conv3x3_first_wgrad(const void* dy, int lddy, const float* x_nchw, float* dW, void* ws, size_t ws_bytes,
                             int N, int C, int H, int W, int Cout, int dtype, void* stream);
+/* The same with the BatchNorm + ReLU backward of enc1[1..2] (models.py:29-30) fused in: `da` is the gradient of the
+ * activated tensor and `y` the layer's pre-BN output; the conv-output gradient fea_bn_relu_bwd_apply would write,
+ * scale * (g - coef[2c] - xhat * coef[2c+1]) with g = da * [relu(bn(y)) > 0], is formed on the fly and never stored (the
+ * first layer has no data gradient, train_direct.py:104: the weight gradient is its only reader).  part[rows][Cout][2],
+ * rows = fea_first_wgrad_bnbwd_rows(): slot 0 = per-split sums of that gradient (conv bias gradient via fea_reduce_partials). */
+int fea_first_wgrad_bnbwd_rows(int N, int H, int W, int Cout);
+int fea_conv3x3_first_wgrad_bnbwd(const void* da, int ldda, const void* y, int ldy, const float* scale, const float* shift,
+                                  const float* save_mean, const float* save_invstd, const float* coef,
+                                  const float* x_nchw, float* dW, float* part, void* ws, size_t ws_bytes,
+                                  int N, int C, int H, int W, int Cout, int dtype, void* stream);
 
 /* ---- implicit-GEMM convolutions (MFMA) ----------------------------------- */
 
@@ -284,6 +294,17 @@ int fea_head_loss_sums(const void* a, int lda, const float* w, const float* bias
 int fea_head_loss_bwd(const void* a, int lda, const float* w, const float* bias, const uint8_t* target,
                       const double* sums, float* loss, void* da, int ldda, float* part, float gscale,
                       int N, int H, int W, int Cin, int Ccls, int dtype, void* stream);
+/* The same two entry points with BatchNorm + ReLU of dec1[4..5] (models.py:32-33) applied in their loaders: `y` is the
+ * PRE-BatchNorm output of dec1[3]; relu(y * bn_scale + bn_shift), rounded to the compute dtype as fea_bn_relu_pool stores
+ * it, is formed in registers, so the activated tensor out = self.out(d1) reads (models.py:46) is never written.
+ * bf16, H*W % 16 == 0, up to 6 classes: fea_head_loss_bn_supported(). */
+int fea_head_loss_bn_supported(int N, int H, int W, int Ccls, int dtype);
+int fea_head_loss_sums_bn(const void* y, int ldy, const float* bn_scale, const float* bn_shift, const float* w, const float* bias,
+                          const uint8_t* target, float* logits, double* sums, float* part, int N, int H, int W, int Cin,
+                          int Ccls, int dtype, void* stream);
+int fea_head_loss_bwd_bn(const void* y, int ldy, const float* bn_scale, const float* bn_shift, const float* w, const float* bias,
+                         const uint8_t* target, const double* sums, float* loss, void* da, int ldda, float* part, float gscale,
+                         int N, int H, int W, int Cin, int Ccls, int dtype, void* stream);
 /* target = grey > 127 */
 int fea_binarise(const uint8_t* grey, uint8_t* out, long long n, void* stream);
 

@@ -753,3 +753,109 @@ def test_pack_batch_equals_the_single_pack_calls(dt):
     for fn, _w, one, many in keep:
         assert torch.equal(one.view(torch.int16 if dt == torch.bfloat16 else torch.int32),
                            many.view(torch.int16 if dt == torch.bfloat16 else torch.int32)), fn
+
+
+@pytest.mark.parametrize("cin", [3, 5])
+@pytest.mark.parametrize("shape", [(2, 32, 64), (1, 40, 72), (3, 64, 96)])
+def test_first_layer_wgrad_with_fused_bn_backward(cin, shape):
+    """fea_conv3x3_first_wgrad_bnbwd == fea_bn_relu_bwd_apply followed by fea_conv3x3_first_wgrad (+ fea_reduce_partials for
+    the conv bias gradient): the conv-output gradient is formed by the same fp32 expression and rounded to bf16 once, so
+    the weight gradients agree to fp32 summation order; also against autograd on the CPU."""
+    dt = torch.bfloat16
+    code = L.dt_code(dt)
+    n, h, w = shape
+    c = 64
+    g = torch.Generator().manual_seed(29)
+    x = rnd(dt, n, cin, h, w, gen=g)
+    y = (rnd(dt, n, c, h, w, gen=g) * 1.5 + 0.2).to(dt).float()
+    da = rnd(dt, n, c, h, w, gen=g)
+    gamma = torch.rand(c, generator=g) + 0.5
+    gamma[::5] *= -1
+    beta = torch.randn(c, generator=g) * 0.2
+    mean = y.mean((0, 2, 3))
+    invstd = torch.rsqrt(y.var((0, 2, 3), unbiased=False) + 1e-5)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    coef = torch.randn(c, 2, generator=g) * 1e-2
+    dev = [t.to(DEV).contiguous() for t in (scale, shift, mean, invstd)]
+    coefd = coef.to(DEV).contiguous()
+    xd = x.to(DEV).contiguous()
+    dad, yd = to_nhwc(da, dt, ld=c + 64, off=64), to_nhwc(y, dt)
+    # separate kernels
+    nblk = L.call("fea_bn_bwd_blocks", n, h, w, c)
+    part = torch.full((max(nblk, 512), c, 2), float("nan"), device=DEV)
+    dy = torch.full((n, h, w, c), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_bn_relu_bwd_apply", view_ptr(dad, 64), c + 64, None, yd, *dev, coefd, dy, part, n, h, w, c, code, S())
+    db_ref = torch.empty(c, device=DEV)
+    L.call("fea_reduce_partials", part, nblk, c, 0, db_ref, S())
+    nbytes = L.load().fea_first_wgrad_ws_bytes(n, h, w, c)
+    ws = torch.empty(nbytes // 4, device=DEV)
+    dW_ref = torch.full((c, cin, 3, 3), float("nan"), device=DEV)
+    L.call("fea_conv3x3_first_wgrad", dy, c, xd, dW_ref, ws, nbytes, n, cin, h, w, c, code, S())
+    # fused
+    rows = L.call("fea_first_wgrad_bnbwd_rows", n, h, w, c)
+    assert 0 < rows <= 256
+    part2 = torch.full((rows, c, 2), float("nan"), device=DEV)
+    dW = torch.full((c, cin, 3, 3), float("nan"), device=DEV)
+    L.call("fea_conv3x3_first_wgrad_bnbwd", view_ptr(dad, 64), c + 64, yd, c, *dev, coefd, xd, dW, part2, ws, nbytes,
+           n, cin, h, w, c, code, S())
+    db = torch.empty(c, device=DEV)
+    L.call("fea_reduce_partials", part2, rows, c, 0, db, S())
+    torch.cuda.synchronize()
+    assert rel_l2(dW.cpu(), dW_ref.cpu()) < 1e-5, rel_l2(dW.cpu(), dW_ref.cpu())
+    assert rel_l2(db.cpu(), db_ref.cpu()) < 1e-5
+    # CPU reference from the stored bf16 gradient of the separate path
+    wz = torch.zeros(c, cin, 3, 3, requires_grad=True)
+    F.conv2d(x, wz, padding=1).backward(from_nhwc(dy, c))
+    check(dW, wz.grad, dt, "fused first-layer wgrad", scale=0.5)
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 24, 40), (1, 1, 16, 16), (3, 4, 32, 32), (2, 5, 8, 12)])
+def test_fused_head_loss_with_batchnorm_in_the_loader(shape):
+    """fea_head_loss_sums_bn / fea_head_loss_bwd_bn (BatchNorm + ReLU of dec1.3 applied to the loaded pre-BN tensor) against
+    fea_bn_relu_pool followed by fea_head_loss_sums / fea_head_loss_bwd: the activation is formed by the same expression and
+    rounded to bf16 the same way, so everything is bit-identical."""
+    dt = torch.bfloat16
+    code = L.dt_code(dt)
+    n, c, h, w = shape
+    assert L.call("fea_head_loss_bn_supported", n, h, w, c, code) == 1
+    assert L.call("fea_head_loss_bn_supported", n, h, w, 7, code) == 0 and L.call("fea_head_loss_bn_supported", n, h, w, c, L.F32) == 0
+    g = torch.Generator().manual_seed(37)
+    y = rnd(dt, n, 64, h, w, gen=g)
+    scale = torch.rand(64, generator=g) + 0.5
+    scale[::6] *= -1
+    shift = torch.randn(64, generator=g) * 0.3
+    wt = torch.randn(c, 64, generator=g) / 4
+    bias = torch.randn(c, generator=g)
+    tgt = (torch.rand(n, c, h, w, generator=g) < 0.2).to(torch.uint8)
+    yd, wd, bd, td = to_nhwc(y, dt, ld=72, off=8), wt.to(DEV), bias.to(DEV), tgt.to(DEV)
+    scd, shd = scale.to(DEV), shift.to(DEV)
+    a = torch.full((n, h, w, 64), float("nan"), dtype=dt, device=DEV)
+    # fea_bn_relu_pool takes a dense y
+    ydense = to_nhwc(y, dt)
+    L.call("fea_bn_relu_pool", ydense, scd, shd, a, 64, None, n, h, w, 64, code, S())
+    nblk = L.call("fea_head_bwd_blocks", n, h, w)
+    res = []
+    for fused in (False, True):
+        lg = torch.full((n, c, h, w), float("nan"), device=DEV)
+        sums = torch.empty(c, 4, dtype=torch.float64, device=DEV)
+        part = torch.empty(nblk * c * 4, device=DEV)
+        loss = torch.empty(1, device=DEV)
+        hpart = torch.empty(nblk * c * 65, device=DEV)
+        da = torch.full((n, h, w, 64), float("nan"), dtype=dt, device=DEV)
+        dW, db = torch.empty(c, 64, device=DEV), torch.empty(c, device=DEV)
+        if fused:
+            L.call("fea_head_loss_sums_bn", view_ptr(yd, 8), 72, scd, shd, wd, bd, td, lg, sums, part, n, h, w, 64, c, code, S())
+            L.call("fea_head_loss_bwd_bn", view_ptr(yd, 8), 72, scd, shd, wd, bd, td, sums, loss, da, 64, hpart, 1.0, n, h, w, 64, c, code, S())
+        else:
+            L.call("fea_head_loss_sums", a, 64, wd, bd, td, lg, sums, part, n, h, w, 64, c, code, S())
+            L.call("fea_head_loss_bwd", a, 64, wd, bd, td, sums, loss, da, 64, hpart, 1.0, n, h, w, 64, c, code, S())
+        L.call("fea_head_bwd_finalize", hpart, nblk, dW, db, 64, c, S())
+        torch.cuda.synchronize()
+        res.append((lg, sums, loss, da, dW, db))
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+    # and the activation itself against torch
+    ref = torch.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    check(from_nhwc(a, 64), ref, dt, "bn + relu")
+    with pytest.raises(L.FeaError):
+        L.call("fea_head_loss_sums_bn", view_ptr(yd, 8), 72, scd, shd, wd, bd, td, None, sums, part, n, h, w, 64, c, L.F32, S())
