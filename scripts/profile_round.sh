@@ -3,7 +3,7 @@
 # its own, counters only: HBM traffic FETCH_SIZE / WRITE_SIZE, MFMA busy).  Usage (on the GPU box, from the repo root):
 #   bash scripts/profile_round.sh r2      -> gpurun_out/prof_r2/*
 set -e
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
