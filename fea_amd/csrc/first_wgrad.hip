@@ -41,7 +41,7 @@ __device__ __forceinline__ int fw_swz(int x) { return ((x >> 1) & 1) | (((x >> 3
 
 template <bool BN, int NW>
 __device__ __forceinline__ void fw_issue(const FirstWgradArgs& g, int m0, int wave, int lane, int tile, char* sb,
-                                         const int (&xdesc)[10], int nxi) {
+                                         const int (&xdesc)[10], int nxi, bool fast = false, int lo_d = 0, int lo_y = 0) {
     constexpr int DYB = BN ? 2 * FW_DY_BYTES : FW_DY_BYTES;      // BN: [da tile][y tile][halo]
     int tt = tile;
     const int tile_x = tt % g.tiles_x; tt /= g.tiles_x;
@@ -51,6 +51,18 @@ __device__ __forceinline__ void fw_issue(const FirstWgradArgs& g, int m0, int wa
     const int H = g.H, W = g.W;
     const __bf16* dimg = g.dy + (long long)n_img * H * W * g.lddy + m0;
     const float* ximg = g.x + (long long)n_img * g.C * H * W;
+    if (fast) {
+        // whole tiles: no bounds checks; a lane's element offset from the tile origin is lo + it * (NW / 4 rows), the origin is uniform
+        const __bf16* dt0 = dimg + (long long)(y0 * W + x0) * g.lddy;
+        const __bf16* yt0 = BN ? g.ybn + ((long long)n_img * H * W + y0 * W + x0) * g.ldy + m0 : nullptr;
+#pragma unroll
+        for (int it = 0; it < 32 / NW; ++it) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(dt0 + lo_d + it * (NW / 4) * W * g.lddy), (lds_void_t*)(sb + (it * NW + wave) * 1024), 16, 0, 0);
+            if constexpr (BN)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(yt0 + lo_y + it * (NW / 4) * W * g.ldy),
+                                                 (lds_void_t*)(sb + FW_DY_BYTES + (it * NW + wave) * 1024), 16, 0, 0);
+        }
+    } else
 #pragma unroll
     for (int it = 0; it < 32 / NW; ++it) {
         const int row = (it * NW + wave) * 8 + (lane >> 3);
@@ -174,10 +186,13 @@ __global__ __launch_bounds__(BN ? 512 : 256) void first_wgrad_kernel(const First
         a0[j] = 0.f;
     }
     const bool partial = (g.H & 7) || (g.W & 31);
+    const bool fast = BN && !partial;
+    const int row0f = wave * 8 + (lane >> 3);
+    const int lo_d = ((row0f >> 5) * g.W + txf) * g.lddy + chunkf * 8, lo_y = ((row0f >> 5) * g.W + txf) * g.ldy + chunkf * 8;
 
     const int t_begin = split * g.tiles_per_split;
     const int t_end = min(t_begin + g.tiles_per_split, g.ntiles);
-    if (t_begin < t_end) fw_issue<BN, NW>(g, m0, wave, lane, t_begin, smem, xdesc, nxi);
+    if (t_begin < t_end) fw_issue<BN, NW>(g, m0, wave, lane, t_begin, smem, xdesc, nxi, fast, lo_d, lo_y);
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int stage = (tile - t_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(BN ? 512 : 256) void first_wgrad_kernel(const First
         if constexpr (BN) {
             char* sb = smem + stage * FW_STAGE;
             // the next tile's loads go first: they are in flight during the transform and the multiplication of this one
-            if (tile + 1 < t_end) fw_issue<true, NW>(g, m0, wave, lane, tile + 1, smem + (stage ^ 1) * FW_STAGE, xdesc, nxi);
+            if (tile + 1 < t_end) fw_issue<true, NW>(g, m0, wave, lane, tile + 1, smem + (stage ^ 1) * FW_STAGE, xdesc, nxi, fast, lo_d, lo_y);
             int y0 = 0, x0 = 0;
             if (partial) {
                 int tt = tile;
