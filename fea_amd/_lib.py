@@ -77,6 +77,8 @@ SIGNATURES = {
     "fea_head_loss_bn_supported": (I, [I, I, I, I, I]),
     "fea_head_loss_sums_bn": (I, [P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "fea_head_loss_bwd_bn": (I, [P, I, P, P, P, P, P, P, P, P, I, P, F, I, I, I, I, I, I, P]),
+    "fea_head_loss_bwd_bnred": (I, [P, I, P, P, P, P, P, P, P, P, P, P, P, F, I, I, I, I, I, I, P]),
+    "fea_head_loss_bwd_bnapply": (I, [P, I, P, P, P, P, P, P, P, P, P, P, I, P, F, I, I, I, I, I, I, P]),
     "fea_bce_dice_sums": (I, [P, P, P, P, I, I, L, P]),
     "fea_loss_blocks": (I, [I, I, L]),
     "fea_bce_dice_sums_static": (I, [P, P, P, I, I, L, P]),

@@ -753,6 +753,17 @@ __device__ __forceinline__ void hl_bn_act(const HlBn& b, u32x4& x0, u32x4& x1) {
     }
 }
 
+// the same, keeping the pre-BN values and the activations as floats (the BatchNorm-backward modes of the backward kernel)
+__device__ __forceinline__ void hl_bn_act_keep(const HlBn& b, u32x4& x0, u32x4& x1, float (&yf)[16], float (&act)[16]) {
+    const bf16x8 y0 = __builtin_bit_cast(bf16x8, x0), y1 = __builtin_bit_cast(bf16x8, x1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { yf[j] = (float)y0[j]; yf[8 + j] = (float)y1[j]; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) act[j] = fmaxf(__builtin_fmaf(yf[j], b.sc[j], b.sh[j]), 0.f);
+    x0 = u32x4{hl_pack(act[0], act[1]), hl_pack(act[2], act[3]), hl_pack(act[4], act[5]), hl_pack(act[6], act[7])};
+    x1 = u32x4{hl_pack(act[8], act[9]), hl_pack(act[10], act[11]), hl_pack(act[12], act[13]), hl_pack(act[14], act[15])};
+}
+
 template <int NE, bool BNA>                        // accumulator registers that hold classes: (classes + 3) / 4
 __global__ __launch_bounds__(256) void head_loss_sums_mfma_kernel(const __bf16* __restrict__ a, int lda, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, const uint8_t* __restrict__ tgt,
@@ -844,13 +855,25 @@ __global__ __launch_bounds__(256) void head_loss_sums_mfma_kernel(const __bf16* 
 #ifndef HL_BWD_AHEAD
 #define HL_BWD_AHEAD 1            // 2 measured the same (0.96 vs 0.95 ms at batch 64 @512^2): the kernel is not waiting for HBM latency
 #endif
-template <int NC, int D, bool BNA>                 // classes the dW accumulators are sized for (4, 6 or 8); tiles of read-ahead
+// MODE 0: da = W^T dlogits is stored, dW / db partial sums go to `part`.
+// MODE 1 (BNA): the first pass of dec1.3's BatchNorm backward instead of the da store: g = da * [relu(bn(y)) > 0] (da rounded to
+//         bf16 as MODE 0 stores it), per-channel sum g and invstd * sum g * (y - mean) -> bn_part[block][64][2]; dW / db as MODE 0.
+//         One wave per SIMD: the dW accumulators and the BatchNorm sums together need ~300 registers.
+// MODE 2 (BNA): da is formed again and dec1.3's BatchNorm backward is applied to it: dy = scale * (g - c1 - xhat * c2) is stored
+//         where MODE 0 stores da (what fea_bn_relu_bwd_apply would write from da and y); per-channel sum dy -> bn_part[block][64][2]
+//         slot 0 (the conv bias gradient); no dW / db.  With MODE 1 and 2 the gradient da (2 GB at batch 64 x 512^2) is never
+//         stored: three reads of y and one store of dy replace store da, read da + y twice, store dy.
+struct HlBnBwd { const float *mu, *is, *coef; float* part; };
+template <int NC, int D, bool BNA, int MODE>       // classes the dW accumulators are sized for (4, 6 or 8); tiles of read-ahead
 __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16* __restrict__ a, int lda, const float* __restrict__ w,
                                                                     const float* __restrict__ bias, const uint8_t* __restrict__ tgt,
                                                                     const double* __restrict__ sums, float* __restrict__ loss,
                                                                     __bf16* __restrict__ da, int ldda, float* __restrict__ part,
                                                                     float gscale, int ntile, int HW, int N, int Ccls,
-                                                                    const float* __restrict__ bn_sc, const float* __restrict__ bn_sh) {
+                                                                    const float* __restrict__ bn_sc, const float* __restrict__ bn_sh,
+                                                                    const HlBnBwd bb) {
+    static_assert(MODE == 0 || BNA, "the BatchNorm-backward modes read the pre-BN tensor");
+    constexpr bool GW = MODE != 2;                   // dW / db accumulation
     constexpr int NE = (NC + 3) / 4;
     __shared__ float red[4][NC * 65];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r16 = lane & 15, q = lane >> 4;
@@ -867,6 +890,16 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
     hl_weights(f, w, bias, Ccls, r16, q);
     HlBn bn;
     hl_bn_load<BNA>(bn, bn_sc, bn_sh, q);
+    // BatchNorm-backward modes: this lane's 16 channels (x0: 8q .., x1: 32 + 8q ..)
+    float bmu[16], bis[16], bc1[16], bc2[16], s0[16], s1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int ch = (j >> 3) * 32 + q * 8 + (j & 7);
+        bmu[j] = MODE != 0 ? bb.mu[ch] : 0.f;
+        bis[j] = MODE == 2 ? bb.is[ch] : 0.f;
+        bc1[j] = MODE == 2 ? bb.coef[2 * ch] : 0.f; bc2[j] = MODE == 2 ? bb.coef[2 * ch + 1] : 0.f;
+        s0[j] = 0.f; s1[j] = 0.f;
+    }
     // GEMM 2 A operand, row block mb: lane (row = lane % 16, q): k-slot j < 4 <-> class q + 4j, slots 4..7 zero.  Row i of
     // block mb is channel 32 (mb / 2) + 8 (i / 4) + 4 (mb % 2) + i % 4: the accumulators of a lane over a block pair are
     // eight consecutive channels.
@@ -893,11 +926,23 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
         lc[e] = (have[e] ? c : q < Ccls ? q : 0) * HW + r16;
     }
     const float itot = gscale / (float)total, ic = gscale / (float)Ccls;
-    float gw[NC][16], gb[NE];
+    // dW on the matrix pipe: dW^T[channel][class] = sum over pixels act^T[channel][pixel] d[pixel][class], four 16-channel M
+    // tiles, k = the tile's 16 pixels (k-slots 16..31 carry zeros in B).  Both operands need the pixel index as k, i.e. a
+    // transpose of what the lanes hold (lane = pixel): the activations go through a per-wave LDS tile and come back through
+    // the transposing read, the (<= 8 x 16) dlogits through a small fp32 table.  d enters as hi + lo bf16 like in the da product.
+    // (On the VALU -- 16 channels x <= 8 classes of fmas per lane and tile, 96 accumulators -- this was 40 % of the kernel's
+    // instructions and kept the BatchNorm-backward mode from fitting two waves per SIMD.)
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+    __shared__ __attribute__((aligned(128))) char tsp[GW ? 4 : 1][3072];     // per wave: [16 px][128 B] activations, [16 classes][16 px] fp32 d
+    char* const my = tsp[GW ? wv : 0];
+    float* const dt = reinterpret_cast<float*>(my + 2048);
+    if constexpr (GW) {
+        for (int i = lane; i < 256; i += 64) dt[i] = 0.f;             // rows of absent classes stay zero
+    }
+    f32x4 G[4];
+    float gb[NE];
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) gw[c][j] = 0.f;
+    for (int t = 0; t < 4; ++t) G[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < NE; ++e) gb[e] = 0.f;
 
@@ -919,9 +964,12 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
         hl_fetch<NE, false>(d, more ? xa : xc, tgt, (long long)k.n * CHW + k.hw, lc);
         xa += xstep; ahead.next(HW);                  // (past the end neither is dereferenced)
     };
-    auto tile = [&](const HlTile<NE>& c) {
+    // (always_inline: in MODE 1 the body is past the inliner's threshold, and a called lambda keeps every captured array in scratch)
+    auto tile = [&](const HlTile<NE>& c) __attribute__((always_inline)) {
         u32x4 x0 = c.x0, x1 = c.x1;
-        hl_bn_act<BNA>(bn, x0, x1);
+        float yf[16], act[16];
+        if constexpr (MODE != 0) hl_bn_act_keep(bn, x0, x1, yf, act);
+        else hl_bn_act<BNA>(bn, x0, x1);
         const f32x4 v = hl_logits(f, x0, x1);
         float d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -949,25 +997,63 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
                 o[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2h[mb]), __builtin_bit_cast(bf16x8, bl), o[h], 0, 0, 0);
                 o[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2l[mb]), __builtin_bit_cast(bf16x8, bh), o[h], 0, 0, 0);
             }
-            *reinterpret_cast<u32x4*>(dp + mp * 32) = u32x4{hl_pack(o[0][0], o[0][1]), hl_pack(o[0][2], o[0][3]),
-                                                            hl_pack(o[1][0], o[1][1]), hl_pack(o[1][2], o[1][3])};
-        }
-        dp += dstep;
-        // dW: the dlogits of this lane's pixel for every class (lane (pixel, c % 4) holds class c in register c / 4) x its 16 channels
-        float xf[16];
-        {
-            const bf16x8 b0 = __builtin_bit_cast(bf16x8, x0), b1 = __builtin_bit_cast(bf16x8, x1);
+            const u32x4 dav = u32x4{hl_pack(o[0][0], o[0][1]), hl_pack(o[0][2], o[0][3]), hl_pack(o[1][0], o[1][1]), hl_pack(o[1][2], o[1][3])};
+            if constexpr (MODE == 0) *reinterpret_cast<u32x4*>(dp + mp * 32) = dav;
+            else {
+                // da as MODE 0 would have stored it (bf16), then the BatchNorm backward of bn_relu_bwd_kernel (elementwise.hip)
+                const bf16x8 dab = __builtin_bit_cast(bf16x8, dav);
+                float dy[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { xf[j] = (float)b0[j]; xf[8 + j] = (float)b1[j]; }
-        }
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (c < Ccls) {                                  // (uniform)
-                const float dc = __shfl(d[c >> 2], r16 + 16 * (c & 3));
-#pragma unroll
-                for (int j = 0; j < 16; ++j) gw[c][j] = __builtin_fmaf(dc, xf[j], gw[c][j]);
+                for (int e = 0; e < 8; ++e) {
+                    const int j = mp * 8 + e;
+                    const float gg = act[j] > 0.f ? (float)dab[e] : 0.f;
+                    if constexpr (MODE == 1) { s0[j] += gg; s1[j] = __builtin_fmaf(gg, yf[j] - bmu[j], s1[j]); }
+                    else {
+                        const float xh = (yf[j] - bmu[j]) * bis[j];
+                        dy[e] = bn.sc[j] * (gg - bc1[j] - xh * bc2[j]);
+                        s0[j] += dy[e];
+                    }
+                }
+                if constexpr (MODE == 2)
+                    *reinterpret_cast<u32x4*>(dp + mp * 32) = u32x4{hl_pack(dy[0], dy[1]), hl_pack(dy[2], dy[3]), hl_pack(dy[4], dy[5]), hl_pack(dy[6], dy[7])};
             }
         }
+        dp += dstep;
+        if constexpr (!GW) return;
+        // dW (see above): lane (pixel r16, q) writes its 16 activations and its dlogits, then reads the transposed operands
+        *reinterpret_cast<u32x4*>(my + r16 * 128 + q * 16) = x0;
+        *reinterpret_cast<u32x4*>(my + r16 * 128 + 64 + q * 16) = x1;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) dt[(q + 4 * e) * 16 + r16] = d[e];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // B: lane (class n = r16, k-group q): d[pixel 8q .. 8q+7][n] for q < 2, zeros for the padding k-slots
+        float dv[8];
+        {
+            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(dt + r16 * 16 + (q & 1) * 8);
+            const f32x4 hi4 = *reinterpret_cast<const f32x4*>(dt + r16 * 16 + (q & 1) * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dv[j] = q < 2 ? lo4[j] : 0.f; dv[4 + j] = q < 2 ? hi4[j] : 0.f; }
+        }
+        const u32x4 dbh = {hl_pack(dv[0], dv[1]), hl_pack(dv[2], dv[3]), hl_pack(dv[4], dv[5]), hl_pack(dv[6], dv[7])};
+        const u32x4 dbl = {hl_pack(hl_lo(dv[0]), hl_lo(dv[1])), hl_pack(hl_lo(dv[2]), hl_lo(dv[3])),
+                           hl_pack(hl_lo(dv[4]), hl_lo(dv[5])), hl_pack(hl_lo(dv[6]), hl_lo(dv[7]))};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // A: lane (channel 16 t + r16, k-group q): pixels 8 (q & 1) .. + 7 (lanes of the padding k-slots re-read real pixels:
+            // their products meet zeros).  Transposing read: lane fetches 4 channels of pixel 8 (q & 1) + 4 u + r16 / 4.
+            s16x4 h2[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                h2[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4_t*)(my + (8 * (q & 1) + 4 * u + (r16 >> 2)) * 128 + (16 * t + 4 * (r16 & 3)) * 2));
+            const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            G[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, dbh), G[t], 0, 0, 0);
+            G[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, dbl), G[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                 // the next tile's writes come after these reads
     };
     // Behind a tile's loads when it is waited for: D fetches of 2 + NE loads and the two da stores of each of the D tiles before
     // it.  The first D tiles have fewer stores behind them: they are waited for outright.
@@ -980,7 +1066,7 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
                 constexpr int s_ = decltype(sc)::value;
                 if (!done) {
                     fetch(ring[(s_ + D) % (D + 1)]);
-                    hl_wait<D * (4 + NE)>(ring[s_]);
+                    hl_wait<D * ((MODE == 1 ? 2 : 4) + NE)>(ring[s_]);
                     tile(ring[s_]);
                     cur.next(HW); xc += xstep;
                     done = cur.t >= ntile;
@@ -990,15 +1076,36 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
         // the repeated fetches still target these registers: keep them out of other use until they have landed
         sfor<0, D + 1>([&](auto ic) { hl_wait<0>(ring[decltype(ic)::value]); });
     }
-    // reduce over the 16 pixel lanes, then over the four waves; lane (0, q) owns channels q*8 .. +7 and 32 + q*8 .. +7
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
+    if constexpr (MODE != 0) {
+        // per-channel sums of the BatchNorm-backward modes: over the 16 pixel lanes, then over the four waves
+        __shared__ float redbn[4][128];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            float x = gw[c][j];
+            float x = s0[j], z = s1[j];
             x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
-            if (r16 == 0) red[wv][c * 65 + (j >> 3) * 32 + q * 8 + (j & 7)] = x;
+            z += __shfl_xor(z, 1); z += __shfl_xor(z, 2); z += __shfl_xor(z, 4); z += __shfl_xor(z, 8);
+            if (r16 == 0) {
+                const int ch = (j >> 3) * 32 + q * 8 + (j & 7);
+                redbn[wv][2 * ch] = x; redbn[wv][2 * ch + 1] = z;
+            }
         }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int ch = threadIdx.x >> 1;
+            float t = (redbn[0][threadIdx.x] + redbn[1][threadIdx.x]) + (redbn[2][threadIdx.x] + redbn[3][threadIdx.x]);
+            if (MODE == 1 && (threadIdx.x & 1)) t *= bb.is[ch];          // sum g * xhat = invstd * sum g * (y - mean)
+            bb.part[(long long)blockIdx.x * 128 + threadIdx.x] = t;
+        }
+        if constexpr (!GW) return;
+        __syncthreads();
+    }
+    // dW: lane (class r16, q) holds channels 16 t + 4 q + e of its class (already summed over the pixels); then over the four waves
+    if (r16 < NC) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wv][r16 * 65 + 16 * t + 4 * q + e] = G[t][e];
+    }
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         float x = gb[e];
@@ -1146,7 +1253,7 @@ static int head_loss_bwd_impl(const char* who, const void* a, int lda, const flo
     hipStream_t s = (hipStream_t)stream;
     const bool mfma = dtype == FEA_BF16 && HW % 16 == 0 && npix * Ccls < (1ll << 31);       // as in fea_head_loss_sums
     FEA_CHECK(!bn_sc || (mfma && bn_sh), FEA_E_UNSUPPORTED_SHAPE, "%s: the fused BatchNorm + ReLU needs bf16 and H*W %% 16 == 0", who);
-#define HLB_LAUNCH(NCV, DV, BNV) hipLaunchKernelGGL((head_loss_bwd_mfma_kernel<NCV, DV, BNV>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, (int)(npix / 16), (int)HW, N, Ccls, bn_sc, bn_sh)
+#define HLB_LAUNCH(NCV, DV, BNV) hipLaunchKernelGGL((head_loss_bwd_mfma_kernel<NCV, DV, BNV, 0>), dim3(nblk), dim3(256), 0, s, (const __bf16*)a, lda, w, bias, target, sums, loss, (__bf16*)da, ldda, part, gscale, (int)(npix / 16), (int)HW, N, Ccls, bn_sc, bn_sh, HlBnBwd{})
     if (mfma && Ccls <= 4) { if (bn_sc) HLB_LAUNCH(4, HL_BWD_AHEAD, true); else HLB_LAUNCH(4, HL_BWD_AHEAD, false); }
     else if (mfma && Ccls <= 6) { if (bn_sc) HLB_LAUNCH(6, HL_BWD_AHEAD, true); else HLB_LAUNCH(6, HL_BWD_AHEAD, false); }
     else if (mfma) {
@@ -1172,4 +1279,54 @@ extern "C" int fea_head_loss_bwd_bn(const void* y, int ldy, const float* bn_scal
                                     int N, int H, int W, int Cin, int Ccls, int dtype, void* stream) {
     FEA_CHECK(bn_scale && bn_shift, FEA_E_BADARG, "fea_head_loss_bwd_bn: null coefficients");
     return head_loss_bwd_impl("fea_head_loss_bwd_bn", y, ldy, bn_scale, bn_shift, w, bias, target, sums, loss, da, ldda, part, gscale, N, H, W, Cin, Ccls, dtype, stream);
+}
+
+#ifndef HL_RED_AHEAD
+#define HL_RED_AHEAD 1            // tiles of read-ahead of the MODE 1 kernel
+#endif
+// dec1.3's BatchNorm backward inside the fused head + loss backward (MODE 1 / MODE 2 of head_loss_bwd_mfma_kernel): two passes over
+// the pre-BN tensor y replace {store da, fea_bn_relu_bwd_reduce, fea_bn_relu_bwd_apply}.  bn_part: [fea_head_bwd_blocks()][64][2].
+static int head_loss_bnbwd_check(const char* who, const void* y, int ldy, const float* w, const float* bias, const uint8_t* target,
+                                 const double* sums, int N, int H, int W, int Cin, int Ccls, int dtype) {
+    FEA_CHECK(y && w && bias && target && sums && N > 0 && H > 0 && W > 0, FEA_E_BADARG, "%s: bad args", who);
+    FEA_CHECK(Cin == 64 && ldy >= 64 && ldy % 8 == 0, FEA_E_UNSUPPORTED_SHAPE, "%s: Cin=%d ldy=%d", who, Cin, ldy);
+    FEA_CHECK(fea_head_loss_bn_supported(N, H, W, Ccls, dtype), FEA_E_UNSUPPORTED_SHAPE, "%s: needs bf16, H*W %% 16 == 0, 1..6 classes", who);
+    FEA_CHECK((uintptr_t)target % 4 == 0, FEA_E_BADARG, "%s: alignment", who);
+    return FEA_OK;
+}
+extern "C" int fea_head_loss_bwd_bnred(const void* y, int ldy, const float* bn_scale, const float* bn_shift, const float* save_mean,
+                                       const float* save_invstd, const float* w, const float* bias, const uint8_t* target,
+                                       const double* sums, float* loss, float* part, float* bn_part, float gscale,
+                                       int N, int H, int W, int Cin, int Ccls, int dtype, void* stream) {
+    const char* who = "fea_head_loss_bwd_bnred";
+    int rc = head_loss_bnbwd_check(who, y, ldy, w, bias, target, sums, N, H, W, Cin, Ccls, dtype);
+    if (rc) return rc;
+    FEA_CHECK(bn_scale && bn_shift && save_mean && save_invstd && part && bn_part, FEA_E_BADARG, "%s: null pointer", who);
+    const long long npix = (long long)N * H * W, HW = (long long)H * W;
+    const int nblk = head_blocks(npix);
+    hipStream_t s = (hipStream_t)stream;
+    const HlBnBwd bb{save_mean, save_invstd, nullptr, bn_part};
+#define HLR_LAUNCH(NCV) hipLaunchKernelGGL((head_loss_bwd_mfma_kernel<NCV, HL_RED_AHEAD, true, 1>), dim3(nblk), dim3(256), 0, s, (const __bf16*)y, ldy, w, bias, target, sums, loss, (__bf16*)nullptr, 64, part, gscale, (int)(npix / 16), (int)HW, N, Ccls, bn_scale, bn_shift, bb)
+    if (Ccls <= 4) HLR_LAUNCH(4); else HLR_LAUNCH(6);
+#undef HLR_LAUNCH
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
+}
+extern "C" int fea_head_loss_bwd_bnapply(const void* y, int ldy, const float* bn_scale, const float* bn_shift, const float* save_mean,
+                                         const float* save_invstd, const float* coef, const float* w, const float* bias,
+                                         const uint8_t* target, const double* sums, void* dy, int lddy, float* bn_part, float gscale,
+                                         int N, int H, int W, int Cin, int Ccls, int dtype, void* stream) {
+    const char* who = "fea_head_loss_bwd_bnapply";
+    int rc = head_loss_bnbwd_check(who, y, ldy, w, bias, target, sums, N, H, W, Cin, Ccls, dtype);
+    if (rc) return rc;
+    FEA_CHECK(bn_scale && bn_shift && save_mean && save_invstd && coef && dy && bn_part && lddy >= 64 && lddy % 8 == 0, FEA_E_BADARG, "%s: bad args", who);
+    const long long npix = (long long)N * H * W, HW = (long long)H * W;
+    const int nblk = head_blocks(npix);
+    hipStream_t s = (hipStream_t)stream;
+    const HlBnBwd bb{save_mean, save_invstd, coef, bn_part};
+#define HLA_LAUNCH(NCV) hipLaunchKernelGGL((head_loss_bwd_mfma_kernel<NCV, 1, true, 2>), dim3(nblk), dim3(256), 0, s, (const __bf16*)y, ldy, w, bias, target, sums, (float*)nullptr, (__bf16*)dy, lddy, (float*)nullptr, gscale, (int)(npix / 16), (int)HW, N, Ccls, bn_scale, bn_shift, bb)
+    if (Ccls <= 4) HLA_LAUNCH(4); else HLA_LAUNCH(6);
+#undef HLA_LAUNCH
+    FEA_LAUNCH_CHECK();
+    return FEA_OK;
 }

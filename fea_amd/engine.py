@@ -246,6 +246,8 @@ class UNetEngine:
             L.call("fea_set_persistent_split", int(os.environ["FEA_AMD_PERSISTENT_SPLIT"]))
         # dec1.3: BatchNorm + ReLU applied inside the fused head + loss kernels' loaders (FEA_AMD_FUSE_HEAD_BN=0: separate pass)
         self.fuse_head_bn = os.environ.get("FEA_AMD_FUSE_HEAD_BN", "1") != "0"
+        # ... and its backward as well (fea_head_loss_bwd_bnred / _bnapply; FEA_AMD_FUSE_HEAD_BNBWD=0: da stored, separate reduce / apply)
+        self.fuse_head_bnbwd = os.environ.get("FEA_AMD_FUSE_HEAD_BNBWD", "1") != "0"
         # enc1.0: BatchNorm backward apply fused into the first layer's weight gradient (FEA_AMD_FUSE_FIRST_WGRAD=0: separate kernels)
         self.fuse_first_wgrad = os.environ.get("FEA_AMD_FUSE_FIRST_WGRAD", "1") != "0"
         self.backward_count = 0        # backward passes run so far (ClipAdamW checks that it steps on one backward's gradients)
@@ -717,11 +719,13 @@ class UNetEngine:
                    pl.bncoef, dY, pl.part, N, h, w, c, code, S)
             L.call("fea_reduce_partials", pl.part, nblk, c, 0, g[name + ".bias"], S)
 
-        def block_bwd(blk, da_full, ld_da, dpool, inp, ld_in, cin, d_in, ld_din, din_stats=None, reduced_tiles=0):
+        def block_bwd(blk, da_full, ld_da, dpool, inp, ld_in, cin, d_in, ld_din, din_stats=None, reduced_tiles=0, pre_applied=False):
+            """pre_applied: X.3's BatchNorm backward has already been applied, ring["dY"] holds its conv-output gradient."""
             h, w = pl.dims[LEVEL[blk]]
             c = CH[blk]
             n3, n0 = f"{blk}.3", f"{blk}.0"
-            bn_bwd(n3, da_full, ld_da, dpool, h, w, c, reduced_tiles=reduced_tiles)
+            if not pre_applied:
+                bn_bwd(n3, da_full, ld_da, dpool, h, w, c, reduced_tiles=reduced_tiles)
             dy3 = ring["dY"]
 
             def wg3():
@@ -783,12 +787,21 @@ class UNetEngine:
                 pl.loss_sums = torch.empty((self.num_classes, 4), dtype=torch.float64, device=self.device)
                 pl.loss_part = torch.empty(nblk * self.num_classes * 4, dtype=torch.float32, device=self.device)
                 pl.loss = torch.empty(1, dtype=torch.float32, device=self.device)
+            head_bnbwd = False
             if getattr(pl, "head_bn", False):
                 cfh = pl.coef["dec1.3"]
                 L.call("fea_head_loss_sums_bn", pl.y["dec1.3"], 64, cfh["scale"], cfh["shift"], P["out.weight"], P["out.bias"], tg, None,
                        pl.loss_sums, pl.loss_part, N, H, W, 64, self.num_classes, code, S)
-                L.call("fea_head_loss_bwd_bn", pl.y["dec1.3"], 64, cfh["scale"], cfh["shift"], P["out.weight"], P["out.bias"], tg,
-                       pl.loss_sums, pl.loss, pl.G[0], 64, pl.head_part, 1.0, N, H, W, 64, self.num_classes, code, S)
+                if self.fuse_head_bnbwd:
+                    # dec1.3's BatchNorm backward inside the head's backward too: da is never stored (two more passes over y
+                    # instead of store da / reduce(da, y) / apply(da, y))
+                    head_bnbwd = True
+                    L.call("fea_head_loss_bwd_bnred", pl.y["dec1.3"], 64, cfh["scale"], cfh["shift"], cfh["mean"], cfh["invstd"],
+                           P["out.weight"], P["out.bias"], tg, pl.loss_sums, pl.loss, pl.head_part, pl.part, 1.0,
+                           N, H, W, 64, self.num_classes, code, S)
+                else:
+                    L.call("fea_head_loss_bwd_bn", pl.y["dec1.3"], 64, cfh["scale"], cfh["shift"], P["out.weight"], P["out.bias"], tg,
+                           pl.loss_sums, pl.loss, pl.G[0], 64, pl.head_part, 1.0, N, H, W, 64, self.num_classes, code, S)
             else:
                 L.call("fea_head_loss_sums", pl.a3["dec1"], 64, P["out.weight"], P["out.bias"], tg, None, pl.loss_sums, pl.loss_part,
                        N, H, W, 64, self.num_classes, code, S)
@@ -803,6 +816,14 @@ class UNetEngine:
             L.call("fea_head_bwd", dl, pl.a3["dec1"], 64, P["out.weight"], pl.G[0], 64, pl.head_part, N, H, W, 64, self.num_classes, code, S)
         L.call("fea_head_bwd_finalize", pl.head_part, nblk, g["out.weight"], g["out.bias"], 64, self.num_classes, S)
         done("out.weight", "out.bias")
+        if dl is None and head_bnbwd:
+            cfh = pl.coef["dec1.3"]
+            L.call("fea_bn_bwd_finalize", pl.part, nblk, N * H * W, P["dec1.4.weight"], cfh["invstd"],
+                   g["dec1.4.weight"], g["dec1.4.bias"], pl.bncoef, 64, S)
+            dY1 = next_dY()
+            L.call("fea_head_loss_bwd_bnapply", pl.y["dec1.3"], 64, cfh["scale"], cfh["shift"], cfh["mean"], cfh["invstd"], pl.bncoef,
+                   P["out.weight"], P["out.bias"], tg, pl.loss_sums, dY1, 64, pl.part, 1.0, N, H, W, 64, self.num_classes, code, S)
+            L.call("fea_reduce_partials", pl.part, nblk, 64, 0, g["dec1.3.bias"], S)
         # decoder
         pre = 0          # > 0: pl.part holds the BN-backward partial sums of the next block's X.3 layer
         for k in (1, 2, 3, 4):
@@ -810,7 +831,8 @@ class UNetEngine:
             c = CH[blk]
             # the dgrad that writes dcat[k] also emits per-tile channel sums of it: channels
             # [0,c) summed over pixels = the transposed conv's bias gradient
-            block_bwd(blk, pl.G[0], c, None, pl.cat[k], 2 * c, 2 * c, pl.dcat[k], 2 * c, din_stats=pl.stats, reduced_tiles=pre)
+            block_bwd(blk, pl.G[0], c, None, pl.cat[k], 2 * c, 2 * c, pl.dcat[k], 2 * c, din_stats=pl.stats, reduced_tiles=pre,
+                      pre_applied=(k == 1 and dl is None and head_bnbwd))
             hl, wl = pl.dims[k]
             src = pl.a3[f"dec{k + 1}"] if k < 4 else pl.a3["bottleneck"]
             L.call("fea_reduce_partials_n", pl.stats, pm[f"{blk}.0"][1] or L.call("fea_conv_num_tiles", N, 2 * hl, 2 * wl), 2 * c, c, 0,

@@ -305,6 +305,19 @@ int fea_head_loss_sums_bn(const void* y, int ldy, const float* bn_scale, const f
 int fea_head_loss_bwd_bn(const void* y, int ldy, const float* bn_scale, const float* bn_shift, const float* w, const float* bias,
                          const uint8_t* target, const double* sums, float* loss, void* da, int ldda, float* part, float gscale,
                          int N, int H, int W, int Cin, int Ccls, int dtype, void* stream);
+/* dec1[4..5]'s BatchNorm + ReLU BACKWARD inside the fused head + loss backward as well: the gradient da of the activated
+ * tensor is never stored.  _bnred = fea_head_loss_bwd_bn without the da store, plus the first pass of the BatchNorm backward
+ * (what fea_bn_relu_bwd_reduce computes from da and y) -> bn_part[fea_head_bwd_blocks()][64][2]; after fea_bn_bwd_finalize,
+ * _bnapply forms da again and stores dy = the conv-output gradient fea_bn_relu_bwd_apply would write (bit-identical), with
+ * per-block sums of dy in bn_part slot 0 (conv bias gradient via fea_reduce_partials).  Same support as the _bn forms. */
+int fea_head_loss_bwd_bnred(const void* y, int ldy, const float* bn_scale, const float* bn_shift, const float* save_mean,
+                            const float* save_invstd, const float* w, const float* bias, const uint8_t* target,
+                            const double* sums, float* loss, float* part, float* bn_part, float gscale,
+                            int N, int H, int W, int Cin, int Ccls, int dtype, void* stream);
+int fea_head_loss_bwd_bnapply(const void* y, int ldy, const float* bn_scale, const float* bn_shift, const float* save_mean,
+                              const float* save_invstd, const float* coef, const float* w, const float* bias,
+                              const uint8_t* target, const double* sums, void* dy, int lddy, float* bn_part, float gscale,
+                              int N, int H, int W, int Cin, int Ccls, int dtype, void* stream);
 /* target = grey > 127 */
 int fea_binarise(const uint8_t* grey, uint8_t* out, long long n, void* stream);
 

@@ -859,3 +859,71 @@ def test_fused_head_loss_with_batchnorm_in_the_loader(shape):
     check(from_nhwc(a, 64), ref, dt, "bn + relu")
     with pytest.raises(L.FeaError):
         L.call("fea_head_loss_sums_bn", view_ptr(yd, 8), 72, scd, shd, wd, bd, td, None, sums, part, n, h, w, 64, c, L.F32, S())
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 24, 40), (1, 1, 16, 16), (3, 4, 32, 32)])
+def test_fused_head_loss_with_batchnorm_backward(shape):
+    """fea_head_loss_bwd_bnred / fea_head_loss_bwd_bnapply (dec1.3's BatchNorm backward inside the head's backward, da never
+    stored) against fea_head_loss_bwd_bn -> fea_bn_relu_bwd_reduce -> fea_bn_bwd_finalize -> fea_bn_relu_bwd_apply:
+    dW / db / loss and the conv-output gradient dy bit-identical, the BatchNorm sums to fp32 summation order."""
+    dt = torch.bfloat16
+    code = L.dt_code(dt)
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(39)
+    y = rnd(dt, n, 64, h, w, gen=g)
+    gamma = torch.rand(64, generator=g) + 0.5
+    gamma[::6] *= -1
+    beta = torch.randn(64, generator=g) * 0.3
+    mean = y.mean((0, 2, 3))
+    invstd = torch.rsqrt(y.var((0, 2, 3), unbiased=False) + 1e-5)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    wt = torch.randn(c, 64, generator=g) / 4
+    bias = torch.randn(c, generator=g)
+    tgt = (torch.rand(n, c, h, w, generator=g) < 0.2).to(torch.uint8)
+    yd, wd, bd, td = to_nhwc(y, dt), wt.to(DEV), bias.to(DEV), tgt.to(DEV)
+    cf = [t.to(DEV).contiguous() for t in (scale, shift, mean, invstd)]
+    gam = gamma.to(DEV)
+    nblk = L.call("fea_head_bwd_blocks", n, h, w)
+    sums = torch.empty(c, 4, dtype=torch.float64, device=DEV)
+    part = torch.empty(nblk * c * 4, device=DEV)
+    L.call("fea_head_loss_sums_bn", yd, 64, cf[0], cf[1], wd, bd, td, None, sums, part, n, h, w, 64, c, code, S())
+    # reference chain
+    loss_r = torch.empty(1, device=DEV)
+    hpart = torch.empty(nblk * c * 65, device=DEV)
+    da = torch.full((n, h, w, 64), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_head_loss_bwd_bn", yd, 64, cf[0], cf[1], wd, bd, td, sums, loss_r, da, 64, hpart, 1.0, n, h, w, 64, c, code, S())
+    dW_r, db_r = torch.empty(c, 64, device=DEV), torch.empty(c, device=DEV)
+    L.call("fea_head_bwd_finalize", hpart, nblk, dW_r, db_r, 64, c, S())
+    nb = L.call("fea_bn_bwd_blocks", n, h, w, 64)
+    bpart = torch.zeros(max(nb, nblk), 64, 2, device=DEV)
+    L.call("fea_bn_relu_bwd_reduce", da, 64, None, yd, *cf, bpart, n, h, w, 64, code, S())
+    red_ref = bpart[:nb].double().sum(0).cpu()
+    dgam_r, dbet_r, coef_r = torch.empty(64, device=DEV), torch.empty(64, device=DEV), torch.empty(64, 2, device=DEV)
+    L.call("fea_bn_bwd_finalize", bpart, nb, n * h * w, gam, cf[3], dgam_r, dbet_r, coef_r, 64, S())
+    dy_r = torch.full((n, h, w, 64), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_bn_relu_bwd_apply", da, 64, None, yd, *cf, coef_r, dy_r, bpart, n, h, w, 64, code, S())
+    dbias_r = torch.empty(64, device=DEV)
+    L.call("fea_reduce_partials", bpart, nb, 64, 0, dbias_r, S())
+    # fused chain
+    loss = torch.empty(1, device=DEV)
+    hpart2 = torch.empty(nblk * c * 65, device=DEV)
+    bpart2 = torch.full((nblk, 64, 2), float("nan"), device=DEV)
+    L.call("fea_head_loss_bwd_bnred", yd, 64, *cf, wd, bd, td, sums, loss, hpart2, bpart2, 1.0, n, h, w, 64, c, code, S())
+    dW, db = torch.empty(c, 64, device=DEV), torch.empty(c, device=DEV)
+    L.call("fea_head_bwd_finalize", hpart2, nblk, dW, db, 64, c, S())
+    torch.cuda.synchronize()
+    red = bpart2.double().sum(0).cpu()
+    dgam, dbet, coef = torch.empty(64, device=DEV), torch.empty(64, device=DEV), torch.empty(64, 2, device=DEV)
+    L.call("fea_bn_bwd_finalize", bpart2, nblk, n * h * w, gam, cf[3], dgam, dbet, coef, 64, S())
+    # the apply pass is compared with the reference's coefficients, so that dy can be compared bit for bit
+    dy = torch.full((n, h, w, 80), float("nan"), dtype=dt, device=DEV)
+    L.call("fea_head_loss_bwd_bnapply", yd, 64, *cf, coef_r, wd, bd, td, sums, view_ptr(dy, 16), 80, bpart2, 1.0, n, h, w, 64, c, code, S())
+    dbias = torch.empty(64, device=DEV)
+    L.call("fea_reduce_partials", bpart2, nblk, 64, 0, dbias, S())
+    torch.cuda.synchronize()
+    assert torch.equal(loss, loss_r) and torch.equal(dW, dW_r) and torch.equal(db, db_r)
+    assert rel_l2(red[:, 0], red_ref[:, 0]) < 1e-5 and rel_l2(red[:, 1], red_ref[:, 1]) < 1e-4, (rel_l2(red[:, 0], red_ref[:, 0]), rel_l2(red[:, 1], red_ref[:, 1]))
+    assert rel_l2(dgam.cpu(), dgam_r.cpu()) < 1e-4 and rel_l2(dbet.cpu(), dbet_r.cpu()) < 1e-5
+    assert torch.equal(dy[..., 16:].contiguous().view(torch.int16), dy_r.view(torch.int16)), "conv-output gradient differs from fea_bn_relu_bwd_apply's"
+    assert torch.isnan(dy[..., :16].float()).all()
+    assert (dbias - dbias_r).abs().max().item() <= 1e-4 * dy_r.float().abs().sum((0, 1, 2)).max().item() + 1e-6
