@@ -46,3 +46,28 @@ def test_no_cpu_fallback_in_product():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
                 assert "import_module(\"oracle" not in text and "__import__(\"oracle" not in text
+
+
+def test_asm_hazard_checker_finds_an_early_use_of_a_pending_load():
+    """scripts/check_asm_hazards.py (run by the Makefile on head_loss.hip, whose global loads are inline asm retired by
+    counted waits): a use of a load's destination before the vmcnt that retires it, and any scratch access, are findings."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import check_asm_hazards as C
+    clean = """
+_Z4kernv:
+	global_load_dwordx4 v[10:13], v[2:3], off
+	global_load_dwordx4 v[14:17], v[2:3], off offset:64
+	v_add_f32_e32 v1, v4, v5
+	s_waitcnt vmcnt(1)
+	v_add_f32_e32 v1, v10, v11
+	s_waitcnt vmcnt(0)
+	v_add_f32_e32 v1, v14, v15
+	s_endpgm
+"""
+    early = clean.replace("s_waitcnt vmcnt(1)\n\tv_add_f32_e32 v1, v10, v11", "s_waitcnt vmcnt(1)\n\tv_add_f32_e32 v1, v10, v16")
+    spill = clean.replace("\tv_add_f32_e32 v1, v4, v5", "\tscratch_store_dword off, v4, off")
+    assert C.scan(clean, "kern") == 0
+    assert C.scan(early, "kern") == 1
+    assert C.scan(spill, "kern") == 1
+    assert C.scan(clean, "no_such_kernel") == 2
