@@ -90,6 +90,18 @@ struct TapSched {
 #ifndef IG_GATHER_REGS
 #define IG_GATHER_REGS 1
 #endif
+#ifndef IG_FAST_ADDR
+#define IG_FAST_ADDR 1       // precomputed LDS addresses + unrolled taps in the 128-column 3x3 kernel (0: the round-2 loop, for A/B builds)
+#endif
+// One 16-byte-per-lane LDS-DMA piece as a buffer load: descriptor over [base, base + nbytes), per-lane byte offset `voff` (out of
+// range: the lane receives zeros), wave-uniform byte offset `soff`.  A free function on purpose: with the descriptor made inside a
+// lambda of the kernel template, hipcc 7.2 drops the kernel's host stub without a diagnostic.
+__device__ __forceinline__ void ig_buffer_lds16(const void* base, int nbytes, char* lds, int voff, int soff) {
+    typedef __attribute__((address_space(3))) void lds_v_t;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nbytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_v_t*)lds, 16, voff, soff, 0, 0);
+}
+
 template <typename T, int MODE, int BN, int EPI, int TWS>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     constexpr int CK = Elem<T>::CK, EPC = Elem<T>::EPC;
@@ -503,6 +515,105 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
                 }
             }
         }
+    } else if constexpr (MODE == 0 && BF && TWS == 5 && BN == 128 && IG_FAST_ADDR) {
+        // 8x32 tile, weights through LDS (BN = 128): as the branch below, with every LDS address precomputed.  The loop was
+        // ISSUE-bound: ~90 VALU of address arithmetic per tap and wave (row, swizzle, shift, add for 11 A and 4 B addresses)
+        // beside 64 MFMAs that hold the issue port for 8 of their 16 cycles each -- two waves per SIMD then need > 2,048 issue cycles
+        // per 2,048 cycles of matrix pipe (removing the per-tap barriers or the halo staging changed nothing).  A
+        // wave's 128 pixels are 4 tile rows x 2 halves of 16: m tile -> halo row wm*4 + (m >> 1), x = (m & 1)*16 + r16, and
+        // +16 halo rows leave the swizzle unchanged, so odd tiles are an immediate offset (2,048 B) on the even tile's address:
+        // 6 (halo rows incl. dy) x 3 (dx) base addresses cover every tap; taps are compile-time constants (loop unrolled).
+        uint32_t abase[6][3], bbase[4];
+        // LDS-DMA as buffer loads: 32-bit per-lane offsets (no 64-bit address arithmetic for the compiler to hoist out of the
+        // unrolled taps and spill), the tap / chunk part is the scalar offset operand, padding lanes take an out-of-range offset
+        int woff[W_PASSES];                           // a lane's byte offset inside one tap's [Cout][64] weight slab
+#pragma unroll
+        for (int j = 0; j < W_PASSES; ++j) {
+            const int row = j * 32 + (tid >> 3);
+            woff[j] = ((cout0 + row) * CK + ((sc ^ swz(row)) * EPC)) * (int)sizeof(T);
+        }
+        const int wslab = g.Cout * CK * (int)sizeof(T), wbytes = 9 * g.Cin * g.Cout * (int)sizeof(T), abytes = (int)(g.x_img_stride * sizeof(T));
+        auto stage_Wf = [&](int kc, auto bufc) {
+#pragma unroll
+            for (int j = 0; j < W_PASSES; ++j)
+                ig_buffer_lds16(wg, wbytes, ldsW + decltype(bufc)::value * W_BYTES + (j * 4 + wave) * 1024, woff[j], kc * wslab);
+        };
+        int aoff[A_PASSES];                           // a lane's byte offset inside the image (chunk 0), out of range for padding
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            bool ok;
+            const int off = a_desc(i, ok);
+            aoff[i] = ok ? off * (int)sizeof(T) : (int)0xfffffff0u;
+        }
+        auto stage_Af = [&](int chunk) {
+#pragma unroll
+            for (int i = 0; i < A_PASSES; ++i)
+                ig_buffer_lds16(xg, abytes, ldsA + (i * 4 + wave) * 1024, aoff[i], chunk * CK * (int)sizeof(T));
+        };
+#pragma unroll
+        for (int hr = 0; hr < 6; ++hr)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int row = (wm * 4 + hr) * (TW + 2) + r16 + dx;
+                abase[hr][dx] = lds_a0 + row * 128 + ((q16 ^ swz(row)) << 4);
+            }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bbase[n] = lds_w0 + b_row16[n] * 128 + ((q16 ^ swz(b_row16[n])) << 4);
+        auto rdi = [&](u32x4& dst, uint32_t addr, auto offc) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(offc)::value) : "memory");
+        };
+        auto rd_a = [&](u32x4& dst, auto dyc, auto dxc, auto mc, auto ksc) {          // A fragment of m tile `m`, k-step ks, tap (dy, dx)
+            constexpr int dy = decltype(dyc)::value, dx = decltype(dxc)::value, m = decltype(mc)::value, ks = decltype(ksc)::value;
+            if constexpr (ks == 0) rdi(dst, abase[(m >> 1) + dy][dx], std::integral_constant<int, (m & 1) * 2048>{});
+            else                   rdi(dst, abase[(m >> 1) + dy][dx] ^ (1u << 6), std::integral_constant<int, (m & 1) * 2048>{});
+        };
+        auto compute_fast = [&](auto tapc) {
+            constexpr int tap = decltype(tapc)::value, dy = tap / 3, dx = tap % 3, buf = tap & 1;
+            constexpr int tn = tap == 8 ? 0 : tap + 1, dyn = tn / 3, dxn = tn % 3;      // (after tap 8: a harmless look-ahead)
+            typedef TapSched<MT16> TS;
+            constexpr int S = TS::S;
+            u32x4 Br[2][4];
+            sfor<0, 4>([&](auto nc) { rdi(Br[0][decltype(nc)::value], bbase[decltype(nc)::value], std::integral_constant<int, buf * W_BYTES>{}); });
+            sfor<0, S>([&](auto sc_) {
+                constexpr int s_ = decltype(sc_)::value, ks = s_ / MT16, m = s_ % MT16;
+                constexpr int N = s_ == 0 ? 0 : (s_ == 1 ? TS::nb(0) + 1 : (s_ == 2 ? TS::nb(0) + TS::nb(1) + 2 : TS::nb(s_ - 2) + TS::nb(s_ - 1) + 2));
+                if constexpr (m == 0)
+                    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ArC[s_ % 4]), "+v"(Br[ks][0]), "+v"(Br[ks][1]), "+v"(Br[ks][2]), "+v"(Br[ks][3])
+                                 : "n"(N) : "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ArC[s_ % 4]) : "n"(N));
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc16[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ArC[s_ % 4]),
+                                                                          __builtin_bit_cast(bf16x8, Br[ks][n]), acc16[m][n], 0, 0, 0);
+                sfor<0, TS::nb(s_)>([&](auto jc) {
+                    constexpr int j = TS::bfirst(s_) + decltype(jc)::value;
+                    rdi(Br[1][j], bbase[j] ^ (1u << 6), std::integral_constant<int, buf * W_BYTES>{});
+                });
+                if constexpr (s_ + 3 < S)
+                    rd_a(ArC[(s_ + 3) % 4], std::integral_constant<int, dy>{}, std::integral_constant<int, dx>{},
+                         std::integral_constant<int, (s_ + 3) % MT16>{}, std::integral_constant<int, (s_ + 3) / MT16>{});
+                else
+                    rd_a(ArC[(s_ + 3) % 4], std::integral_constant<int, dyn>{}, std::integral_constant<int, dxn>{},
+                         std::integral_constant<int, s_ + 3 - S>{}, std::integral_constant<int, 0>{});
+            });
+        };
+        for (int ch = 0; ch < nchunks; ++ch) {
+            __syncthreads();                       // previous chunk fully consumed
+            stage_Wf(ch * 9, std::integral_constant<int, 0>{});
+            stage_Af(ch);
+            __syncthreads();                       // (drains the LDS-DMA: vmcnt(0) before the barrier)
+            sfor<0, 3>([&](auto mc) {
+                rd_a(ArC[decltype(mc)::value], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, mc, std::integral_constant<int, 0>{});
+            });
+            sfor<0, 9>([&](auto tapc) {
+                constexpr int tap = decltype(tapc)::value;
+                // the buffer of tap+1 was last read in tap-1, which every wave has left
+                if constexpr (tap < 8) stage_Wf(ch * 9 + tap + 1, std::integral_constant<int, (tap + 1) & 1>{});
+                compute_fast(tapc);
+                if constexpr (tap < 8) __syncthreads();
+            });
+        }
     } else if (MODE == 0 && BF) {
         const int HW2 = TW + 2;
 #ifdef IG_STAMPS
@@ -530,7 +641,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
                 const int tn = tap == 8 ? 0 : tap + 1, dyn = tn / 3, dxn = tn - dyn * 3;   // (after tap 8: a harmless look-ahead)
                 compute_cont(dy * HW2 + dx, dyn * HW2 + dxn, tap & 1, [&]() {});
                 ISTAMP(3);
+#ifndef IG_EXP_NO_TAP_BARRIER          // EXPERIMENT (racy, wrong results): upper bound of what removing the per-tap weight barrier could gain
                 if (tap < 8) __syncthreads();
+#else
+                if (tap < 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 ISTAMP(4);
             }
         }
@@ -902,7 +1017,8 @@ static int check_common(const char* who, const void* x, int ldx, const void* w, 
     FEA_CHECK(ldx >= Cin && ldx % 8 == 0 && ldy % 8 == 0, FEA_E_BADARG, "%s: ldx=%d ldy=%d", who, ldx, ldy);
     FEA_CHECK(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)w % 16 == 0), FEA_E_BADARG,
               "%s: pointers must be 16-byte aligned", who);
-    FEA_CHECK((long long)H * W * ldx < (1ll << 31) && (long long)4 * H * W * ldy < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE,
+    // (input: BYTE offsets inside one image are 32-bit -- the halo pieces of the 128-column kernel are buffer loads of an image-sized descriptor)
+    FEA_CHECK((long long)H * W * ldx * (dtype == FEA_BF16 ? 2 : 4) < (1ll << 31) && (long long)4 * H * W * ldy < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE,
               "%s: image too large for 32-bit in-image offsets", who);
     return FEA_OK;
 }
