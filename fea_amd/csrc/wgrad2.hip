@@ -101,6 +101,38 @@ __device__ __forceinline__ void wg2_issue_piece(const Wgrad2Args& g, const __bf1
         }
     }
 }
+// FAST pieces with everything that does not depend on the piece made ONCE per tile (Wg2Tile): the image descriptors, the tile's
+// byte offsets and its edge bits.  As separate calls of wg2_issue_piece every piece redid them under its own `if (has_next)`
+// -- ~25 scalar instructions and a branch per piece, ten pieces per tile, in the in-order stream between the MFMAs.  "No next
+// tile" is folded into the offsets (far out of range: the lanes receive zeros into the stage nobody reads): no branch at all.
+struct Wg2Tile { __amdgpu_buffer_rsrc_t prs, qrs; int ptoff, qtoff; unsigned edge; };
+template <int TWS>
+__device__ __forceinline__ Wg2Tile wg2_tile(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg, int tile_x, int tile_y, int n_img, bool live) {
+    constexpr int TW = 1 << TWS, TH = 256 / TW;
+    Wg2Tile t;
+    t.prs = __builtin_amdgcn_make_buffer_rsrc((void*)(pg + (long long)n_img * g.p_img_stride), 0, (int)(g.p_img_stride * 2), 0x00020000);
+    t.qrs = __builtin_amdgcn_make_buffer_rsrc((void*)(qg + (long long)n_img * g.q_img_stride), 0, (int)(g.q_img_stride * 2), 0x00020000);
+    const int org = (tile_y * TH) * g.W + tile_x * TW;
+    t.ptoff = live ? org * g.ldp * 2 : 0x7ff00000;
+    t.qtoff = live ? org * g.ldq * 2 : 0x7ff00000;
+    t.edge = (tile_y == 0 ? 1u : 0u) | (tile_y == g.tiles_y - 1 ? 2u : 0u) | (tile_x == 0 ? 4u : 0u) | (tile_x == g.tiles_x - 1 ? 8u : 0u) | 16u;
+    return t;
+}
+template <int IT>
+__device__ __forceinline__ void wg2_piece_fast(const Wg2Tile& t, const int (&pdesc)[4], const int (&qdesc)[6], unsigned qfl, int wave, char* sb) {
+    constexpr int QROWS = 352, PBYTES = 256 * 128;
+    if constexpr (IT < 4) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(t.prs, (lds_void_t*)(sb + (IT * 8 + wave) * 1024), 16, t.ptoff + pdesc[IT], 0, 0, 0);
+    } else {
+        constexpr int it = IT - 4;
+        if (it * 8 + wave < QROWS / 8) {
+            const unsigned f = (qfl >> (5 * it)) & t.edge & 31u;
+            const int voff = f ? (int)0xfffffff0u : t.qtoff + qdesc[it];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(t.qrs, (lds_void_t*)(sb + PBYTES + (it * 8 + wave) * 1024), 16, voff, 0, 0, 0);
+        }
+    }
+}
+
 template <int TWS, bool FAST>
 __device__ __forceinline__ void wg2_issue(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
                                           const int (&pdesc)[4], const int (&qdesc)[6], unsigned qfl, int wave,
@@ -116,13 +148,20 @@ __device__ __forceinline__ void lds_tr(u32x2& dst, uint32_t addr) {
 }
 // s_waitcnt lgkmcnt(N), tied to the fragments it retires so that the MFMA that
 // consumes them cannot be hoisted above it.
+// (No register operands: with "+v" ties hipcc pads a hazard s_nop in front of every MFMA -- 80 per tile and wave in a loop that
+// is short of issue slots.  The sched_barrier keeps the consuming MFMA, and everything else, on its side of the wait.)
+#ifndef WG2_TIED_WAITS
+#define WG2_TIED_WAITS 0
+#endif
 template <int N>
 __device__ __forceinline__ void wg2_wait(u32x2& a0, u32x2& a1, u32x2& b0, u32x2& b1) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : "n"(N));
+    if constexpr (WG2_TIED_WAITS) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : "n"(N));
+    else { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); }
 }
 template <int N>
 __device__ __forceinline__ void wg2_wait(u32x2& b0, u32x2& b1) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(N));
+    if constexpr (WG2_TIED_WAITS) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(N));
+    else { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); }
 }
 
 template <int NT> struct Wg2Frag { u32x2 a[2]; u32x2 b[NT][2]; };
@@ -212,8 +251,11 @@ __device__ __forceinline__ void wg2_step(const Wgrad2Args& g, const __bf16* pg, 
                                          const int (&pcol)[(1 << TWS) / 16][2], const int (&qcol)[(1 << TWS) / 16][2][3],
                                          f32x16 (&acc)[NT] WG2_PH_PARAM) {
     constexpr int XSEG = (1 << TWS) / 16, PBYTES = 256 * 128;
+    Wg2Tile nt{};
+    if constexpr (FAST) nt = wg2_tile<TWS>(g, pg, qg, ntx, nty, has_next ? nn : 0, has_next);
     auto piece = [&](auto ic) {
-        if (has_next) wg2_issue_piece<TWS, decltype(ic)::value, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, ntx, nty, nn, dma);
+        if constexpr (FAST) wg2_piece_fast<decltype(ic)::value>(nt, pdesc, qdesc, qfl, wave, dma);
+        else { if (has_next) wg2_issue_piece<TWS, decltype(ic)::value, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, ntx, nty, nn, dma); }
     };
     WSTAMP(2);
     uint32_t pa[XSEG][2], qa[XSEG][2][3];
