@@ -81,6 +81,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 #ifndef P_PIN2
 #define P_PIN2 7
 #endif
+// A fragments retired per counted wait (2 or 4): the loop is ~97 % issue-bound, a wait is an issue slot
+#ifndef P_WAIT_EVERY
+#define P_WAIT_EVERY 4
+#endif
+#ifndef P_WAIT_EVERY_OVL
+#define P_WAIT_EVERY_OVL 4
+#endif
 __device__ __forceinline__ void st_out(__bf16* p, const u32x4& v) {
     if constexpr (P_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
     else *reinterpret_cast<u32x4*>(p) = v;
@@ -269,8 +276,9 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
                 constexpr int m = decltype(mc)::value;
                 // one wait per two MFMA pairs (fragments m and m + 1: 6 reads in flight behind them); no register operand,
                 // so the compiler pads no hazard state behind the statement -- the sched_barrier keeps the MFMAs below it
-                if constexpr ((m & 1) == 0) {
-                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(nstep < 18 ? 6 : 6 - m) : "memory");
+                if constexpr ((m & (P_WAIT_EVERY - 1)) == 0) {
+                    // (P_WAIT_EVERY fragments per wait: 8 reads are in flight, the P_WAIT_EVERY oldest are the ones needed; last k-step: 8 - m)
+                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(nstep < 18 ? 8 - P_WAIT_EVERY : (8 - m - P_WAIT_EVERY > 0 ? 8 - m - P_WAIT_EVERY : 0)) : "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -447,8 +455,10 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
             if constexpr (step == 16) { before16(); prime_bias(); }
             sfor<0, 4>([&](auto mc) {
                 constexpr int mm = decltype(mc)::value, m = HALF * 4 + mm, ai = (step & 1) * 4 + mm;
-                if constexpr ((mm & 1) == 0) {      // fragments mm and mm + 1: 6 ring reads in flight behind them (never fewer: no tail)
-                    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                if constexpr ((mm & (P_WAIT_EVERY_OVL - 1)) == 0) {
+                    // fragments mm .. mm + P_WAIT_EVERY_OVL - 1: 8 ring reads are in flight (10 in k-steps 16 / 17, where the next half's two
+                    // bias reads sit between them), the oldest ones are needed (never fewer in flight: no tail)
+                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"((step >= 16 ? 10 : 8) - P_WAIT_EVERY_OVL) : "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll

@@ -453,12 +453,11 @@ __device__ __forceinline__ void wg3_read(Wg3Frag<NT>& f, const uint32_t (&pa)[2]
 
 template <int N>
 __device__ __forceinline__ void wg3_wait_ab(u32x2 (&a)[2][2], u32x2 (&b)[2][2]) {
-    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]),
-                                           "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0);
 }
 template <int N>
 __device__ __forceinline__ void wg3_wait_b(u32x2 (&b)[2][2]) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0);
 }
 
 // k-step S: fragments in `cur`; those of S + 1 are read into `nxt` between the MFMAs of this step.
@@ -522,8 +521,11 @@ __device__ __forceinline__ void wg3_run(const Wgrad2Args& g, const __bf16* pg, c
         const bool has_next = tile + 1 < t_end;
         char* dma = smem + (stage ^ 1) * STAGE;
         const uint32_t rd = lds_base + stage * STAGE;
+        Wg2Tile nt{};
+        if constexpr (FAST) nt = wg2_tile<5>(g, pg, qg, ntx, nty, has_next ? nn : 0, has_next);
         auto piece = [&](auto ic) {
-            if (has_next) wg2_issue_piece<5, decltype(ic)::value, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, ntx, nty, nn, dma);
+            if constexpr (FAST) wg2_piece_fast<decltype(ic)::value>(nt, pdesc, qdesc, qfl, wave, dma);
+            else { if (has_next) wg2_issue_piece<5, decltype(ic)::value, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, ntx, nty, nn, dma); }
         };
         uint32_t pa[2][2], qa[2][2][3];
 #pragma unroll
@@ -683,10 +685,11 @@ int fea_wgrad2_launch(const void* dy, int lddy, const void* x, int ldx, float* d
     // whole tiles and 32-bit in-image byte offsets: the LDS-DMA pieces take the buffer-descriptor form (wg2_issue_piece)
     const int TWl = 1 << p.tws, THl = 256 / TWl;
     const bool fast = H % THl == 0 && W % TWl == 0 && (long long)(H + 2) * W * lddy * 2 < (1ll << 31) && (long long)(H + 2) * W * ldx * 2 < (1ll << 31);
-    // FEA_AMD_WG3=1 selects the 16x16x32 form of the 8x32-tile kernel (wgrad3_kernel).  Measured round 3, same box: correct
-    // (all weight-gradient tests) and 4-7 % SLOWER per launch (64->64 @512^2 1.225 -> 1.308 ms, 256->256 @128^2 0.948 -> 0.995;
-    // step 81.4 -> 82.5 ms): twice the MFMA issues and the same number of 8-byte transposing LDS reads make the loop
-    // issue-bound before the higher clock of the 16x16x32 form can pay.  Off by default.
+    // FEA_AMD_WG3=1 selects the 16x16x32 form of the 8x32-tile kernel (wgrad3_kernel).  Correct on every weight-gradient test.  Measured
+    // round 3, same box: with register-tied waits (a hazard s_nop per MFMA) 4-7 % SLOWER per launch than wgrad2 (the loop holds twice
+    // the MFMA issues beside the same number of 8-byte transposing LDS reads: ~4,750 issue cycles per 4,608 matrix-pipe cycles per
+    // SIMD and tile); with untied waits and per-tile piece invariants 0-6 % FASTER on random data (1024->1024 @32^2: 0.93 -> 0.88 ms)
+    // and equal inside the training step (76.0 vs 76.1 ms).  Off by default.
     static const bool wg3 = getenv("FEA_AMD_WG3") && getenv("FEA_AMD_WG3")[0] == '1';
     if (p.tws == 5 && wg3) { if (fast) hipLaunchKernelGGL((wgrad3_kernel<true>), grid, block, 0, s, a); else hipLaunchKernelGGL((wgrad3_kernel<false>), grid, block, 0, s, a); }
     else if (p.tws == 5) { if (fast) hipLaunchKernelGGL((wgrad2_kernel<5, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((wgrad2_kernel<5, false>), grid, block, 0, s, a); }
