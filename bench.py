@@ -93,6 +93,8 @@ def kernel_group(name, args, dtype):
         if bf:      # wgrad2.hip: 8x32-pixel tiles when W >= 32, buffer-descriptor pieces on whole tiles (+ its slab reduction)
             tws = 5 if w >= 32 else 4
             fast = h % (256 >> tws) == 0 and w % (1 << tws) == 0
+            if tws == 5 and fast and os.environ.get("FEA_AMD_WG4", "1") != "0":
+                return "void wgrad4_kernel<true>", fl, by          # the 16x16x32, re-tiled form: default on whole 8x32 tiles
             return f"void wgrad2_kernel<{tws}, {'true' if fast else 'false'}>", fl, by
         return "wgrad_kernel (fp32)", fl, by
     if name == "fea_conv3x3":

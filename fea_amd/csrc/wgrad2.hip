@@ -639,6 +639,234 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const Wgrad2Args g) {
 }
 
 // ---------------------------------------------------------------------------
+// wgrad4: the 16x16x32 kernel re-tiled for fewer LDS reads per MFMA (within what 8 waves of 256 registers hold).
+//
+// Same workgroup tile, LDS image, swizzle and LDS-DMA pieces as wgrad3.  Wave w: ci half h = w & 1 (two 16-column N tiles), ALL 64
+// co (four 16-row M tiles), tap group G = w >> 1: taps 2G and 2G + 1 in every k-step, and tap 8 in the k-steps S with
+// (S & 3) == G (each of the four groups sums two of the eight tile rows of tap 8; the four partial sums meet in the epilogue
+// in a fixed order).  Every wave thus multiplies 18 (tap, k-step) pairs of 8 MFMAs per tile -- balanced -- and reads 8 A + 8 or 12
+// B fragments per k-step: 0.94 transposing reads per MFMA against 1.2-1.25 in wgrad2 / wgrad3, whose waves own 32 co only.
+template <int G, int S> __device__ constexpr int wg4_nt() { return 2 + (((S & 3) == G) ? 1 : 0); }
+template <int G> __device__ constexpr int wg4_tap(int slot) { return slot < 2 ? 2 * G + slot : 8; }
+struct Wg4Frag { u32x2 a[4][2]; u32x2 b[3][2][2]; };      // A: [M tile][read], B: [tap slot][N tile][read]
+
+template <int G, int S, int R>
+__device__ __forceinline__ void wg4_read(Wg4Frag& f, const uint32_t (&pa)[4][2], const uint32_t (&qa)[2][2][3]) {
+    constexpr int HW2 = 34;
+    if constexpr (R < 8) {
+        lds_tr<S * 32 * 128>(f.a[R >> 1][R & 1], pa[R >> 1][R & 1]);
+    } else {
+        constexpr int sl = (R - 8) / 4, n = ((R - 8) / 2) % 2, hf = (R - 8) % 2, tap = wg4_tap<G>(sl), dy = tap / 3, dx = tap % 3;
+        lds_tr<(S + dy) * HW2 * 128>(f.b[sl][n][hf], qa[n][hf][dx]);
+    }
+}
+template <int N> __device__ __forceinline__ void wg4_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int G, int S, typename PieceFn>
+__device__ __forceinline__ void wg4_kstep(Wg4Frag& cur, Wg4Frag& nxt, const uint32_t (&pa)[4][2], const uint32_t (&qa)[2][2][3],
+                                          f32x4 (&acc)[3][4][2], PieceFn&& piece) {
+    constexpr int NT = wg4_nt<G, S>(), NRD = 8 + 4 * NT;
+    constexpr bool more = S + 1 < 8;
+    constexpr int NRDN = more ? 8 + 4 * wg4_nt<G, (S + 1) & 7>() : 0;
+    sfor<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        // the next step's reads are dealt over this step's taps; `behind` = reads issued after the ones tap t needs
+        constexpr int cnt = (NRDN + NT - 1 - t) / NT;
+        constexpr int start = [] { int s_ = 0; for (int u = 0; u < t; ++u) s_ += (NRDN + NT - 1 - u) / NT; return s_; }();
+        constexpr int behind = NRD - (12 + 4 * t) + start;
+        wg4_wait<(behind < 15 ? behind : 15)>();
+        u32x4 af[4], bf[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = u32x4{cur.a[i][0].x, cur.a[i][0].y, cur.a[i][1].x, cur.a[i][1].y};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bf[i] = u32x4{cur.b[t][i][0].x, cur.b[t][i][0].y, cur.b[t][i][1].x, cur.b[t][i][1].y};
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf[ni]),
+                                                                         acc[t][mi][ni], 0, 0, 0);
+        if constexpr (more) {
+            sfor<0, cnt>([&](auto rc) { wg4_read<G, S + 1, start + decltype(rc)::value>(nxt, pa, qa); });
+        }
+        // the ten LDS-DMA pieces of the next tile: WG4_PIECE_STEPS k-steps carry them, so that the last ones have
+        // 8 - WG4_PIECE_STEPS k-steps (~300 cycles each) to land before the tile's barrier
+#ifndef WG4_PIECE_STEPS
+#define WG4_PIECE_STEPS 3        // 5 (two pieces per k-step) measured 0-1.5 % slower, 8 (one per k-step: the last land too late) 4-6 % slower
+#endif
+        if constexpr (WG4_PIECE_STEPS == 8) {
+            if constexpr (t == 1) piece(std::integral_constant<int, S>{});
+            if constexpr (t == 0 && S < 2) piece(std::integral_constant<int, 8 + S>{});
+        } else if constexpr (WG4_PIECE_STEPS == 3) {
+            if constexpr (t < 2 && 4 * S + 2 * t < 10) piece(std::integral_constant<int, 4 * S + 2 * t>{});
+            if constexpr (t < 2 && 4 * S + 2 * t + 1 < 10) piece(std::integral_constant<int, 4 * S + 2 * t + 1>{});
+        } else {
+            if constexpr (t < 2 && 2 * S + t < 10) piece(std::integral_constant<int, 2 * S + t>{});
+        }
+    });
+    if constexpr (more) wg4_kstep<G, S + 1>(nxt, cur, pa, qa, acc, piece);
+}
+
+template <int G, bool FAST>
+__device__ __forceinline__ void wg4_run(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
+                                        const int (&pdesc)[4], const int (&qdesc)[6], unsigned qfl, int wave, int t_begin, int t_end,
+                                        char* smem, uint32_t (&pa)[4][2], uint32_t (&qa)[2][2][3], int h) {
+    constexpr int STAGE = (256 + 352) * 128;
+    f32x4 acc[3][4][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[t][i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int ntx, nty, nn;
+    {
+        int tt = t_begin;
+        ntx = tt % g.tiles_x; tt /= g.tiles_x;
+        nty = tt % g.tiles_y; nn = tt / g.tiles_y;
+    }
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int stage = (tile - t_begin) & 1;
+        if (++ntx == g.tiles_x) { ntx = 0; if (++nty == g.tiles_y) { nty = 0; ++nn; } }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // this wave's LDS-DMA has landed; barrier: tile complete, other stage free
+        const bool has_next = tile + 1 < t_end;
+        char* dma = smem + (stage ^ 1) * STAGE;
+        Wg2Tile nt{};
+        if constexpr (FAST) nt = wg2_tile<5>(g, pg, qg, ntx, nty, has_next ? nn : 0, has_next);
+        auto piece = [&](auto ic) {
+            if constexpr (FAST) wg2_piece_fast<decltype(ic)::value>(nt, pdesc, qdesc, qfl, wave, dma);
+            else { if (has_next) wg2_issue_piece<5, decltype(ic)::value, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, ntx, nty, nn, dma); }
+        };
+        Wg4Frag f0, f1;
+        sfor<0, 8 + 4 * wg4_nt<G, 0>()>([&](auto rc) { wg4_read<G, 0, decltype(rc)::value>(f0, pa, qa); });
+        wg4_kstep<G, 0>(f0, f1, pa, qa, acc, piece);
+        // the fragment addresses follow the stage ring in place (no second set of address registers)
+        const int delta = stage ? -STAGE : STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) pa[i][t] += delta;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) qa[i][t][dx] += delta;
+    }
+    __syncthreads();                     // every wave is done reading the stages
+    float* ot = reinterpret_cast<float*>(smem);       // [64 co][64 ci][9]
+    const int lane = threadIdx.x & 63, gi = lane >> 4, li = lane & 15;
+    auto put = [&](int slot, int tap, bool add) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float* o = ot + ((mi * 16 + 4 * gi + e) * 64 + h * 32 + ni * 16 + li) * 9 + tap;
+                    *o = add ? *o + acc[slot][mi][ni][e] : acc[slot][mi][ni][e];
+                }
+    };
+    put(0, 2 * G, false);
+    put(1, 2 * G + 1, false);
+    // tap 8: the four groups' partial sums, added in group order (fixed: bit-identical from run to run)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r == G) put(2, 8, r != 0);
+        __syncthreads();
+    }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(512, 2) void wgrad4_kernel(const Wgrad2Args g) {
+    constexpr int TW = 32, TH = 8, HW2 = TW + 2;
+    constexpr int QROWS = 352;
+    constexpr int PBYTES = 256 * 128, QBYTES = QROWS * 128, STAGE = PBYTES + QBYTES;
+    constexpr int NPI = 4, NQI = 6;
+    __shared__ __attribute__((aligned(128))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = wave & 1, grp = wave >> 1;
+    const int gi = lane >> 4, li = lane & 15;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntp = g.nmt * g.nnt;
+    const int tp = lid % ntp, split = lid / ntp;
+    const int m0 = (tp / g.nnt) * 64, n0 = (tp % g.nnt) * 64;
+
+    // ---- fragment addresses of stage 0 (kept up to date in place by wg4_run) --------------------
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    uint32_t pa[4][2], qa[2][2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int x = 8 * gi + 4 * t + (li >> 2);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int chp = mi * 16 + 4 * (li & 3);
+            pa[mi][t] = lds_base + x * 128 + (((chp >> 3) ^ swzw3(x)) << 4) + (chp & 7) * 2;
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int chq = h * 32 + ni * 16 + 4 * (li & 3);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int hx = x + dx;
+                qa[ni][t][dx] = lds_base + PBYTES + hx * 128 + (((chq >> 3) ^ swzw3(hx)) << 4) + (chq & 7) * 2;
+            }
+        }
+    }
+
+    // ---- LDS-DMA descriptors (as wgrad3_kernel) -------
+    int pdesc[NPI], qdesc[NQI];
+    unsigned qfl = 0;
+    {
+        const int rsub = lane >> 3, cpos = lane & 7;
+#pragma unroll
+        for (int it = 0; it < NPI; ++it) {
+            const int row = (it * 8 + wave) * 8 + rsub;
+            const int ty = row >> 5, tx = row & (TW - 1);
+            if constexpr (FAST) pdesc[it] = (ty * g.W + tx) * g.ldp * 2 + ((cpos ^ swzw3(tx)) << 4);
+            else pdesc[it] = (ty + 1) | ((tx + 1) << 8) | ((cpos ^ swzw3(tx)) << 24);
+        }
+#pragma unroll
+        for (int it = 0; it < NQI; ++it) {
+            const int row = (it * 8 + wave) * 8 + rsub;
+            const int hy = row / HW2, hx = row - hy * HW2;
+            const int inval = hy >= TH + 2 ? 1 : 0;
+            if constexpr (FAST) {
+                qdesc[it] = ((hy - 1) * g.W + (hx - 1)) * g.ldq * 2 + ((cpos ^ swzw3(hx)) << 4);
+                const unsigned f = (hy == 0 ? 1u : 0u) | (hy == TH + 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == TW + 1 ? 8u : 0u) | (inval ? 16u : 0u);
+                qfl |= f << (5 * it);
+            } else qdesc[it] = hy | (hx << 8) | (inval << 16) | ((cpos ^ swzw3(hx)) << 24);
+        }
+    }
+
+    const __bf16* __restrict__ pg = g.p + m0;
+    const __bf16* __restrict__ qg = g.q + n0;
+    const int t_begin = split * g.tiles_per_split;
+    const int t_end = min(t_begin + g.tiles_per_split, g.ntiles);
+
+    if (t_begin < t_end) {
+        int tt = t_begin;
+        const int tx = tt % g.tiles_x; tt /= g.tiles_x;
+        wg2_issue<5, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, tx, tt % g.tiles_y, tt / g.tiles_y, smem);
+    }
+    if (WG2_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(WG2_PRIO);
+    if (grp == 0)      wg4_run<0, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, t_begin, t_end, smem, pa, qa, h);
+    else if (grp == 1) wg4_run<1, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, t_begin, t_end, smem, pa, qa, h);
+    else if (grp == 2) wg4_run<2, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, t_begin, t_end, smem, pa, qa, h);
+    else               wg4_run<3, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, t_begin, t_end, smem, pa, qa, h);
+    const float* ot = reinterpret_cast<const float*>(smem);
+    float* dst = g.out + (long long)split * g.out_split_stride + ((long long)m0 * g.Nn + n0) * 9;
+    for (int i = tid; i < 64 * 144; i += 512) {
+        const int row = i / 144, c4 = i - row * 144;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * 576 + c4 * 4);
+        *reinterpret_cast<f32x4*>(dst + (long long)row * g.Nn * 9 + c4 * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
 struct Wgrad2Plan { int tws, tiles_x, tiles_y, ntiles, splits, tiles_per_split, nmt, nnt; };
 
 static Wgrad2Plan wgrad2_plan(int N, int H, int W, int M, int Nn) {
@@ -691,7 +919,11 @@ int fea_wgrad2_launch(const void* dy, int lddy, const void* x, int ldx, float* d
     // SIMD and tile); with untied waits and per-tile piece invariants 0-6 % FASTER on random data (1024->1024 @32^2: 0.93 -> 0.88 ms)
     // and equal inside the training step (76.0 vs 76.1 ms).  Off by default.
     static const bool wg3 = getenv("FEA_AMD_WG3") && getenv("FEA_AMD_WG3")[0] == '1';
-    if (p.tws == 5 && wg3) { if (fast) hipLaunchKernelGGL((wgrad3_kernel<true>), grid, block, 0, s, a); else hipLaunchKernelGGL((wgrad3_kernel<false>), grid, block, 0, s, a); }
+    // wgrad4_kernel (16x16x32, re-tiled) is the default on whole 8x32 tiles: 6-8 % faster per launch than wgrad2 on random data
+    // (1024->1024 @32^2: 0.90 -> 0.84 ms, 1,480 TF/s), step 76.7 -> 75.35 ms same-box.  FEA_AMD_WG4=0 selects wgrad2 (A/B runs).
+    static const bool wg4 = !(getenv("FEA_AMD_WG4") && getenv("FEA_AMD_WG4")[0] == '0');
+    if (p.tws == 5 && wg4 && fast) hipLaunchKernelGGL((wgrad4_kernel<true>), grid, block, 0, s, a);      // (whole tiles only: the general pieces spill there)
+    else if (p.tws == 5 && wg3) { if (fast) hipLaunchKernelGGL((wgrad3_kernel<true>), grid, block, 0, s, a); else hipLaunchKernelGGL((wgrad3_kernel<false>), grid, block, 0, s, a); }
     else if (p.tws == 5) { if (fast) hipLaunchKernelGGL((wgrad2_kernel<5, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((wgrad2_kernel<5, false>), grid, block, 0, s, a); }
     else            { if (fast) hipLaunchKernelGGL((wgrad2_kernel<4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((wgrad2_kernel<4, false>), grid, block, 0, s, a); }
     FEA_LAUNCH_CHECK();
