@@ -74,7 +74,10 @@ __device__ __forceinline__ void sfor(F&& f) {
 // bf16 conv3x3 with Cout (GEMM N) not a multiple of 128 runs the 64-column kernel, which
 // loads its weight fragments global -> VGPR and wants them packed in fragment order
 // (igemm.hip DB path, elementwise.hip pack_conv3x3_kernel).  One rule for both sides.
-__host__ __device__ inline bool fea_conv3x3_frag_pack(int gemm_n, int elem_bytes) { return elem_bytes == 2 && gemm_n % 128 != 0; }
+#ifndef IG_DB128
+#define IG_DB128 0     // 1: the 128-column 3x3 kernel also takes its weight fragments global -> VGPR (fragment-ordered pack, no weight tile in LDS)
+#endif
+__host__ __device__ inline bool fea_conv3x3_frag_pack(int gemm_n, int elem_bytes) { return elem_bytes == 2 && (gemm_n % 128 != 0 || IG_DB128); }
 
 // Deterministic sum of the pixel-split slabs of the weight-gradient kernels: out[i] = sum over sp of slab[sp][i], i in float4
 // units.  With hundreds of splits and a small weight (64 -> 64: 256 splits of 147 KB) one thread per element is a chain of

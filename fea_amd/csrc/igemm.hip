@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
     // bf16 3x3: the weight (B) fragments go global -> VGPR directly, one tap ahead
     // (fragment-ordered pack, 1 KB contiguous per wave-instruction): no weight tile
     // in LDS and NO per-tap barrier; the A halo tile is the only LDS resident.
-    constexpr bool DB = MODE == 0 && sizeof(T) == 2 && BN == 64;   // (BN = 128: doubling the L2 weight traffic costs more than the barrier)
+    constexpr bool DB = MODE == 0 && sizeof(T) == 2 && (BN == 64 || IG_DB128);   // (BN = 128: doubling the L2 weight traffic costs more than the barrier)
     constexpr bool GR = MODE == 2 && IG_GATHER_REGS;   // (MODE 1 measured slower with it: 128->64 @256^2 0.80 -> 0.96 ms)
     constexpr int NWBUF = DB ? 0 : ((MODE == 0 || GR) ? 2 : 1);
     constexpr int W_BYTES = BN * 128;
@@ -703,8 +703,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
             const int ch = kc - tap * nchunks;
             const int tap_off = MODE == 2 ? ((tap >> 1) * (2 * W) + (tap & 1)) * g.ldx : 0;
             __syncthreads();                       // previous k-chunk consumed
+#ifdef IG_EXP_NO_STAGE_GEMM
+            if (kc == 0) {       // EXPERIMENT (wrong results): staging only for the first chunk = what hiding it completely could gain
+#endif
             stage_W(kc, 0);
             stage_A(ch, tap_off);
+#ifdef IG_EXP_NO_STAGE_GEMM
+            }
+#endif
             __syncthreads();
             compute(0, 0);
         }

@@ -729,14 +729,22 @@ __device__ __forceinline__ void wg4_run(const Wgrad2Args& g, const __bf16* pg, c
         const int stage = (tile - t_begin) & 1;
         if (++ntx == g.tiles_x) { ntx = 0; if (++nty == g.tiles_y) { nty = 0; ++nn; } }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef WG4_EXP_NO_BARRIER       // EXPERIMENT (racy): no per-tile barrier
         __syncthreads();                 // this wave's LDS-DMA has landed; barrier: tile complete, other stage free
+#endif
         const bool has_next = tile + 1 < t_end;
         char* dma = smem + (stage ^ 1) * STAGE;
         Wg2Tile nt{};
+#ifdef WG4_EXP_HOT_DMA          // EXPERIMENT (wrong results): every tile's pieces come from tile 1 of image 0 (cache-hot): issue + LDS-write cost without the memory system
+        if constexpr (FAST) nt = wg2_tile<5>(g, pg, qg, 1, 1, 0, true);
+#else
         if constexpr (FAST) nt = wg2_tile<5>(g, pg, qg, ntx, nty, has_next ? nn : 0, has_next);
+#endif
         auto piece = [&](auto ic) {
+#ifndef WG4_EXP_NO_DMA       // EXPERIMENT (wrong results): no LDS-DMA after the first tile
             if constexpr (FAST) wg2_piece_fast<decltype(ic)::value>(nt, pdesc, qdesc, qfl, wave, dma);
             else { if (has_next) wg2_issue_piece<5, decltype(ic)::value, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, ntx, nty, nn, dma); }
+#endif
         };
         Wg4Frag f0, f1;
         sfor<0, 8 + 4 * wg4_nt<G, 0>()>([&](auto rc) { wg4_read<G, 0, decltype(rc)::value>(f0, pa, qa); });
