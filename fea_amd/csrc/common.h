@@ -124,6 +124,9 @@ static inline void fea_launch_slab_reduce(const float* slab, float* out, int spl
 // host side -----------------------------------------------------------------
 void fea_set_error(const char* fmt, ...);
 int fea_wg_split(void);      // api.hip: fea_set_persistent_split
+// upgemm.hip: ConvTranspose2d forward on the persistent GEMM; false = shape not served (*rc untouched), true = launched (*rc = status)
+bool fea_upg_fwd(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
+                 hipStream_t stream, int* rc);
 #define FEA_CHECK(cond, code, ...) do { if (!(cond)) { fea_set_error(__VA_ARGS__); return (code); } } while (0)
 #define FEA_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
     fea_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return FEA_E_LAUNCH; } } while (0)

@@ -1150,6 +1150,7 @@ extern "C" int fea_upconv2x2_fwd(const void* x, int ldx, const void* w, const fl
     int rc = check_common("fea_upconv2x2_fwd", x, ldx, w, y, ldy, N, H, W, Cin, Cout, dtype);
     if (rc) return rc;
     FEA_CHECK(ldy >= Cout, FEA_E_BADARG, "fea_upconv2x2_fwd: ldy=%d < Cout=%d", ldy, Cout);
+    if (dtype == FEA_BF16 && fea_upg_fwd(x, ldx, w, bias, y, ldy, N, H, W, Cin, Cout, (hipStream_t)stream, &rc)) return rc;
     IgemmArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = nullptr;
     a.ldx = ldx; a.ldy = ldy; a.H = H; a.W = W; a.Cin = Cin; a.Cout = 4 * Cout; a.Cup = Cout;
