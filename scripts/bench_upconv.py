@@ -46,6 +46,18 @@ for (h, ci, co) in ((32, 1024, 512), (64, 512, 256), (128, 256, 128), (256, 128,
             res[on] = timeit(lambda: L.call("fea_upconv2x2_fwd", x, ci, wp, bias, cat, 2 * co, N, h, w, ci, co, code, S))
         print(f"fwd N{N} {h}x{w} {ci}->{co}: igemm {res['0']:.3f} ms ({flops / res['0'] * 1e-9:.0f} TF/s)   persistent {res['1']:.3f} ms "
               f"({flops / res['1'] * 1e-9:.0f} TF/s)", flush=True)
+    elif what == "wgrad":
+        x = torch.randn(N, h, w, ci, generator=g).to(BF).to(DEV)
+        dy = torch.randn(N, 2 * h, 2 * w, 2 * co, generator=g).to(BF).to(DEV)
+        dW = torch.empty((ci, co, 2, 2), device=DEV)
+        res = {}
+        for on in ("0", "1"):
+            os.environ["FEA_AMD_WU256"] = on
+            nbytes = L.load().fea_wgrad_ws_bytes(2, N, h, w, ci, co, code)
+            ws = torch.empty(max(nbytes, 16) // 4, device=DEV)
+            res[on] = timeit(lambda: L.call("fea_upconv2x2_wgrad", x, ci, dy, 2 * co, dW, ws, nbytes, N, h, w, ci, co, code, S))
+        print(f"wgrad N{N} {h}x{w} {ci}->{co}: 128-ch {res['0']:.3f} ms ({flops / res['0'] * 1e-9:.0f} TF/s)   256-ch {res['1']:.3f} ms "
+              f"({flops / res['1'] * 1e-9:.0f} TF/s)", flush=True)
     else:
         dy = torch.randn(N, 2 * h, 2 * w, 2 * co, generator=g).to(BF).to(DEV)
         y = torch.randn(N, h, w, ci, generator=g).to(BF).to(DEV)
