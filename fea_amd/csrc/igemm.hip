@@ -534,6 +534,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
         }
         const int wslab = g.Cout * CK * (int)sizeof(T), wbytes = 9 * g.Cin * g.Cout * (int)sizeof(T), abytes = (int)(g.x_img_stride * sizeof(T));
         auto stage_Wf = [&](int kc, auto bufc) {
+#ifdef IG_EXP_NO_STAGE_W      // EXPERIMENT (wrong results): the weight tile is staged once = what its LDS fill traffic costs
+            if (kc > 1) return;
+#endif
 #pragma unroll
             for (int j = 0; j < W_PASSES; ++j)
                 ig_buffer_lds16(wg, wbytes, ldsW + decltype(bufc)::value * W_BYTES + (j * 4 + wave) * 1024, woff[j], kc * wslab);
@@ -601,6 +604,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs g) {
         for (int ch = 0; ch < nchunks; ++ch) {
             __syncthreads();                       // previous chunk fully consumed
             stage_Wf(ch * 9, std::integral_constant<int, 0>{});
+#ifdef IG_EXP_NO_STAGE_A
+            if (ch == 0)       // EXPERIMENT (wrong results): see the branch below
+#endif
             stage_Af(ch);
             __syncthreads();                       // (drains the LDS-DMA: vmcnt(0) before the barrier)
             sfor<0, 3>([&](auto mc) {

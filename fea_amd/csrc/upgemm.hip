@@ -39,12 +39,13 @@ struct UpgArgs {
     int Cup;                  // EPI 1: channels per output quadrant
     int W;                    // input image width (power of two >= 16)
     int tiles_per_walk;
+    unsigned long long* dbg;  // U_STAMPS builds only: shader cycles of every workgroup
 };
 
 constexpr int U_REG = 32768;                   // one stage of one operand: 256 rows x 128 B
 constexpr int U_NST = 16;                      // 16-byte stores per wave and tile
 #ifndef U_PREFETCH
-#define U_PREFETCH 1
+#define U_PREFETCH 0       // 1: one discarded piece per wave and chunk pulls the next tile's first pixel rows into L2 (measured: no gain, see below)
 #endif
 
 // XOR of a 128-byte row's 16-byte chunk index (igemm.hip swz: conflict-free ds_read_b128 for every base row)
@@ -84,6 +85,9 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
     const int t1 = min(t0 + g.tiles_per_walk, g.ntiles);
     if (t0 >= t1) return;
     const int NC = g.NC;
+#ifdef U_STAMPS
+    const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- fragment read addresses: pixel row wm*128 + m*16 + r16, weight row wn*64 + n*16 + r16, chunk q16 (+4 in k-step 1) ----
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -112,10 +116,11 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
     char* const dstA = smem + wave * 1024;
     char* const dstB = smem + 2 * U_REG + wave * 1024;
 
-    // The walkers of one XCD start their K loop a fraction of K apart (the K order is free as long as both operands agree): a
-    // weight line is then touched by one of them every 1/J of a tile time and stays in the XCD's L2 (4 MB), where walkers in step
-    // touch it once per tile time, with 6 MB of tiles flowing through L2 in between -- every weight read a miss served at the
-    // Infinity Cache's rate, half the L2's.
+    // The column groups of one tile range start their K loop NC / ntn chunks apart (the K order is free as long as both operands
+    // agree; U_ROT 2).  Run in step, the eight workgroups that share a pixel tile ask for the same lines at the same moment, all
+    // behind the one HBM miss, and every workgroup of the chip reads the same 128-byte column of its rows: 0.279 / 0.355 / 0.466 ms
+    // on the three deep levels in step, 0.261 / 0.324 / 0.432 apart.  (U_ROT 1 staggers the walkers of an XCD instead -- meant to
+    // keep the weight lines in L2 -- and measured 0.290 / 0.359 / 0.466; both, U_ROT 3: as 2.)
     const int jwalk = slot / g.ntn, J = max(1, (int)(gridDim.x >> 3) / g.ntn);
 #ifndef U_ROT
 #define U_ROT 2
@@ -152,7 +157,8 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
         else                 upg_piece<U_AUX_W>(wbase, pnbW, dstB + STG * U_REG + (i - 4) * 8192, voffB, psoB + (i - 4) * 8192);
     };
 
-    // L2 prefetch of the NEXT tile's pixel rows.  The column groups of a tile range run their K loops NC / ntn chunks apart (rot), so
+    // L2 prefetch of the NEXT tile's pixel rows (U_PREFETCH, off: 0.264 / 0.337 / 0.454 ms with it against 0.263 / 0.327 / 0.430
+    // without on the three deep levels -- the first-reader misses are not what the ring waits for).  The column groups of a tile range run their K loops NC / ntn chunks apart (rot), so
     // each is the first reader of its first few chunks of every tile and finds the rest in L2; those first reads are HBM misses that
     // the two-stage ring (one chunk = ~1 us of lookahead) cannot cover.  One discarded 1 KB piece per wave and chunk, a whole tile
     // time ahead, lands them in L2 first: piece q = it * 8 + wave of the next tile's chunks rot, rot + 1, ... (32 pieces per chunk).
@@ -322,6 +328,9 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
     }
     // the trailing (dead) pieces write zeros into LDS: they must have landed before the workgroup's LDS is handed on
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef U_STAMPS
+    if (tid == 0 && g.dbg) g.dbg[blockIdx.x] = __builtin_amdgcn_s_memtime() - tstart;
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -352,6 +361,9 @@ bool fea_upg_fwd(const void* x, int ldx, const void* w, const float* bias, void*
     if (nwalk < 8) nwalk = 8;
     a.tiles_per_walk = (a.ntiles + nwalk - 1) / nwalk;
     nwalk = ((a.ntiles + a.tiles_per_walk - 1) / a.tiles_per_walk + 7) / 8 * 8;
+#ifdef U_STAMPS
+    a.dbg = getenv("UPG_DBG_PTR") ? (unsigned long long*)strtoull(getenv("UPG_DBG_PTR"), nullptr, 0) : nullptr;
+#endif
     hipLaunchKernelGGL((upg_kernel<1, 1>), dim3((unsigned)(nwalk * a.ntn)), dim3(512), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fea_set_error("fea_upconv2x2_fwd (persistent GEMM): launch failed: %s", hipGetErrorString(e)); *rc = FEA_E_LAUNCH; }

@@ -44,6 +44,14 @@ for (h, ci, co) in ((32, 1024, 512), (64, 512, 256), (128, 256, 128), (256, 128,
         for on in ("0", "1"):
             os.environ["FEA_AMD_UPGEMM"] = on
             res[on] = timeit(lambda: L.call("fea_upconv2x2_fwd", x, ci, wp, bias, cat, 2 * co, N, h, w, ci, co, code, S))
+        if os.environ.get("UPG_STAMPS"):
+            dbg = torch.zeros(4096, dtype=torch.int64, device=DEV)
+            os.environ["UPG_DBG_PTR"] = hex(dbg.data_ptr())
+            L.call("fea_upconv2x2_fwd", x, ci, wp, bias, cat, 2 * co, N, h, w, ci, co, code, S)
+            torch.cuda.synchronize()
+            cyc = dbg[dbg > 0].double()
+            print(f"   workgroup shader cycles: mean {cyc.mean().item():.0f} max {cyc.max().item():.0f} -> clock {cyc.max().item() / res['1'] * 1e-6:.2f} GHz "
+                  f"(if the longest workgroup spans the launch)")
         print(f"fwd N{N} {h}x{w} {ci}->{co}: igemm {res['0']:.3f} ms ({flops / res['0'] * 1e-9:.0f} TF/s)   persistent {res['1']:.3f} ms "
               f"({flops / res['1'] * 1e-9:.0f} TF/s)", flush=True)
     elif what == "wgrad":
