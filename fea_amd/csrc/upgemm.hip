@@ -1,10 +1,11 @@
-// Persistent, software-pipelined GEMM for the transposed-convolution pair (bf16, gfx950).
+// Persistent, software-pipelined GEMM for the transposed-convolution forward (bf16, gfx950).
 //
-// nn.ConvTranspose2d(ci, co, 2, stride=2) (models.py:15-21) is a plain GEMM per pixel: forward M = pixels, K = ci,
-// N = 4 co (column ab*co + c goes to output pixel (2i+a, 2j+b), channel c); its data gradient is M = input pixels,
-// K = 4 taps x co (row of pixel (i,j), tap (a,b) = gradient pixel (2i+a, 2j+b)), N = ci.  The implicit-GEMM kernel of
-// igemm.hip runs them as 256 x 128 tiles whose every 64-channel chunk is staged between two barriers (LDS-DMA issue +
-// its whole memory latency exposed per chunk: 350-940 TF/s).  Here:
+// nn.ConvTranspose2d(ci, co, 2, stride=2) (models.py:15-21) is a plain GEMM per pixel: M = pixels, K = ci, N = 4 co (column
+// ab*co + c goes to output pixel (2i+a, 2j+b), channel c).  The implicit-GEMM kernel of igemm.hip runs it as 256 x 128 tiles
+// whose every 64-channel chunk is staged between two barriers (LDS-DMA issue + its whole memory latency exposed per chunk), and a
+// plain GEMM tile of that size asks the CU's LDS fill path for 47 B/clk at full MFMA rate where ~13 (Infinity Cache) to ~30 (L2)
+// are to be had (MI355X_MICROARCH.md, gather into LDS): 350-940 TF/s.  Here (the data gradient, the same GEMM over gathered rows
+// with K = 4 co, stays on igemm.hip: its fused BatchNorm-backward epilogue does not fit beside 128 accumulators per wave):
 //
 //   * ONE workgroup of 8 waves per CU walks a range of 256-pixel tiles for a fixed 256-column group: wave = 128 pixels x
 //     64 columns (8 x 4 accumulator tiles of v_mfma_f32_16x16x32_bf16, 128 registers), two waves per SIMD so that one wave's
@@ -27,16 +28,16 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 struct UpgArgs {
-    const __bf16* a;          // pixel operand: MODE 1 x [M][lda]; MODE 2 dy [4 M][lda]
+    const __bf16* a;          // pixel operand x [M][lda]
     const __bf16* w;          // packed weights [K / 64][Ntot][64] (fea_pack_upconv2x2)
-    const float* bias;        // EPI 1: [Cup], nullable
-    __bf16* y;                // EPI 1: [4 M][ldy], pixel-shuffled
+    const float* bias;        // [Cup], nullable
+    __bf16* y;                // [4 M][ldy], pixel-shuffled
     int lda, ldy;
     unsigned a_bytes, w_bytes;
     int ntiles;               // M / 256
     int NC;                   // 64-channel chunks per tile (even)
     int Ntot, ntn;            // GEMM N, Ntot / 256
-    int Cup;                  // EPI 1: channels per output quadrant
+    int Cup;                  // channels per output quadrant
     int W;                    // input image width (power of two >= 16)
     int tiles_per_walk;
     unsigned long long* dbg;  // U_STAMPS builds only: shader cycles of every workgroup
@@ -69,7 +70,6 @@ __device__ __forceinline__ uint32_t upg_pack(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
-template <int MODE, int EPI>
 __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
     // [pixel rows stage 0 | stage 1 | weight rows stage 0 | stage 1], 256 rows x 128 B each, then the bias of the column group
     __shared__ __attribute__((aligned(1024))) char smem[4 * U_REG + 2048];
@@ -100,16 +100,9 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
     const int prow = 8 * wave + (lane >> 3);
     const int pchunk = (lane & 7) ^ u_swz(prow);
     int voffA, dA[4];                        // lane offset of the first pixel piece; wave-uniform offsets of the others
-    if constexpr (MODE == 1) {
-        voffA = prow * g.lda * 2 + pchunk * 16;
+    voffA = prow * g.lda * 2 + pchunk * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dA[i] = 64 * i * g.lda * 2;
-    } else {
-        const int wmask = min(g.W, 256) - 1;
-        voffA = (4 * prow - 2 * (prow & wmask)) * g.lda * 2 + pchunk * 16;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dA[i] = (256 * i - 2 * ((64 * i) & wmask)) * g.lda * 2;
-    }
+    for (int i = 0; i < 4; ++i) dA[i] = 64 * i * g.lda * 2;
     const int voffB = prow * 128 + pchunk * 16;
     const __bf16* const wbase = g.w + (long long)nt * 256 * 64;
     const unsigned w_bytes = g.w_bytes - (unsigned)nt * 256u * 128u;
@@ -134,14 +127,7 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
         const bool live = ptile < t1;
         pnbA = live ? g.a_bytes : 0u; pnbW = live ? w_bytes : 0u;
         int pcr = pc + rot; if (pcr >= NC) pcr -= NC;
-        if constexpr (MODE == 1) psoA = (int)((unsigned)ptile * 256u * (unsigned)g.lda * 2u) + pcr * 128;
-        else {
-            const int cpt = g.Cup >> 6;                       // chunks per tap
-            const int tap = pcr / cpt, ch = pcr - tap * cpt;
-            const unsigned pix0 = (unsigned)ptile * 256u;
-            const unsigned jt = g.W >= 256 ? (pix0 & (unsigned)(g.W - 1)) : 0u;
-            psoA = (int)((4u * pix0 - 2u * jt + (unsigned)((tap >> 1) * 2 * g.W + (tap & 1))) * (unsigned)g.lda * 2u) + ch * 128;
-        }
+        psoA = (int)((unsigned)ptile * 256u * (unsigned)g.lda * 2u) + pcr * 128;
         psoB = pcr * g.Ntot * 128;
 #ifdef U_EXP_HOT_DMA      // EXPERIMENT (wrong results): every chunk re-reads the first 64 KB = issue + LDS-write cost without the memory system
         psoA = 0; psoB = 0;
@@ -168,14 +154,7 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
         const bool live = tile + 1 < t1 && g.ntn > 1;
         int pcr = rot + (it >> 2); if (pcr >= NC) pcr -= NC;
         int so;
-        if constexpr (MODE == 1) so = (int)((unsigned)(tile + 1) * 256u * (unsigned)g.lda * 2u) + pcr * 128;
-        else {
-            const int cpt = g.Cup >> 6;
-            const int tap = pcr / cpt, ch = pcr - tap * cpt;
-            const unsigned pix0 = (unsigned)(tile + 1) * 256u;
-            const unsigned jt = g.W >= 256 ? (pix0 & (unsigned)(g.W - 1)) : 0u;
-            so = (int)((4u * pix0 - 2u * jt + (unsigned)((tap >> 1) * 2 * g.W + (tap & 1))) * (unsigned)g.lda * 2u) + ch * 128;
-        }
+        so = (int)((unsigned)(tile + 1) * 256u * (unsigned)g.lda * 2u) + pcr * 128;
         upg_piece<0>(g.a, live ? g.a_bytes : 0u, dump, voffA, so + dA[it & 3]);
 #endif
     };
@@ -183,19 +162,15 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
     // bias of the 256-column group in LDS (behind the stages): added in the epilogue, where the dead weight fragments' registers
     // hold it (as persistent registers, or as the C operand of a tile's first MFMAs, it spilled the kernel)
     float* const blds = reinterpret_cast<float*>(smem + 4 * U_REG);
-    if (tid < 256) blds[tid] = (EPI == 1 && g.bias) ? g.bias[(nt * 256 + tid) % g.Cup] : 0.f;
+    if (tid < 256) blds[tid] = g.bias ? g.bias[(nt * 256 + tid) % g.Cup] : 0.f;
     // output: lane = pixel r16 of accumulator tile m, 8 channels from chl of the 32-column pair j
     const int chl = (q16 & 1) * 16 + (q16 >> 1) * 8;
     int lane_off[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col0 = nt * 256 + wn * 64 + j * 32;
-        if constexpr (EPI == 1) {
-            const int ab = col0 / g.Cup, co0 = col0 - ab * g.Cup;
-            lane_off[j] = (2 * r16 + (ab >> 1) * 2 * g.W + (ab & 1)) * g.ldy + co0 + chl;
-        } else {
-            lane_off[j] = r16 * g.ldy + col0 + chl;
-        }
+        const int ab = col0 / g.Cup, co0 = col0 - ab * g.Cup;
+        lane_off[j] = (2 * r16 + (ab >> 1) * 2 * g.W + (ab & 1)) * g.ldy + co0 + chl;
     }
 
     f32x4 acc[8][4];
@@ -277,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
         // (the last MFMAs are inline asm: the compiler does not pad the accumulators' first VALU read -- 16 passes at most)
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
         f32x4 bv[4];
-        if constexpr (EPI == 1) {
+        {
             // (the address is rebuilt from the lane id here: as a loop invariant it was the one register the kernel spilled, and its
             //  scratch reload is a vmcnt(0) in every tile)
             int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -291,12 +266,10 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int pix0 = pixw + m * 16;
-            long long sbase;
-            if constexpr (EPI == 1) sbase = (long long)(4 * pix0 - 2 * (pix0 & (g.W - 1))) * g.ldy;
-            else                    sbase = (long long)pix0 * g.ldy;
+            const long long sbase = (long long)(4 * pix0 - 2 * (pix0 & (g.W - 1))) * g.ldy;      // output pixel (2i, 2j) of the tile row
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if constexpr (EPI == 1) { acc[m][2 * j] += bv[2 * j]; acc[m][2 * j + 1] += bv[2 * j + 1]; }
+                acc[m][2 * j] += bv[2 * j]; acc[m][2 * j + 1] += bv[2 * j + 1];
                 const uint32_t lo0 = upg_pack(acc[m][2 * j][0], acc[m][2 * j][1]), hi0 = upg_pack(acc[m][2 * j][2], acc[m][2 * j][3]);
                 const uint32_t lo1 = upg_pack(acc[m][2 * j + 1][0], acc[m][2 * j + 1][1]), hi1 = upg_pack(acc[m][2 * j + 1][2], acc[m][2 * j + 1][3]);
                 // odd 16-lane rows of the first operand <-> even rows of the second: every lane ends up with 8 consecutive channels
@@ -364,7 +337,7 @@ bool fea_upg_fwd(const void* x, int ldx, const void* w, const float* bias, void*
 #ifdef U_STAMPS
     a.dbg = getenv("UPG_DBG_PTR") ? (unsigned long long*)strtoull(getenv("UPG_DBG_PTR"), nullptr, 0) : nullptr;
 #endif
-    hipLaunchKernelGGL((upg_kernel<1, 1>), dim3((unsigned)(nwalk * a.ntn)), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL(upg_kernel, dim3((unsigned)(nwalk * a.ntn)), dim3(512), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fea_set_error("fea_upconv2x2_fwd (persistent GEMM): launch failed: %s", hipGetErrorString(e)); *rc = FEA_E_LAUNCH; }
     else *rc = FEA_OK;
