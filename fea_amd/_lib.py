@@ -35,6 +35,7 @@ SIGNATURES = {
     "fea_pack_batch": (I, [P, I, I, I, P]),
     "fea_pack_conv3x3_first": (I, [P, P, I, I, I, P]),
     "fea_conv3x3_first": (I, [P, P, P, P, I, P, I, I, I, I, I, I, P]),
+    "fea_conv3x3_first_rows": (I, [I, I, I, I, I, I]),
     "fea_first_wgrad_ws_bytes": (Z, [I, I, I, I]),
     "fea_conv3x3_first_wgrad": (I, [P, I, P, P, P, Z, I, I, I, I, I, I, P]),
     "fea_first_wgrad_bnbwd_rows": (I, [I, I, I, I]),

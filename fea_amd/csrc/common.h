@@ -124,6 +124,9 @@ static inline void fea_launch_slab_reduce(const float* slab, float* out, int spl
 // host side -----------------------------------------------------------------
 void fea_set_error(const char* fmt, ...);
 int fea_wg_split(void);      // api.hip: fea_set_persistent_split
+// first_conv.hip: the first layer on the persistent kernel; false = shape not served (*rc untouched), true = launched (*rc = status)
+bool fea_first_conv_p(const float* x, const void* w, const float* bias, void* y, int ldy, float* stats, int relu,
+                      int N, int C, int H, int W, int Cout, hipStream_t s, int* rc);
 // upgemm.hip: ConvTranspose2d forward on the persistent GEMM; false = shape not served (*rc untouched), true = launched (*rc = status)
 bool fea_upg_fwd(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
                  hipStream_t stream, int* rc);

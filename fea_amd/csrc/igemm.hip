@@ -1096,6 +1096,10 @@ extern "C" int fea_conv3x3_first(const float* x, const void* w_packed, const flo
     FEA_CHECK(Cout > 0 && Cout % 64 == 0 && ldy >= Cout && ldy % 8 == 0, FEA_E_UNSUPPORTED_SHAPE, "fea_conv3x3_first: Cout=%d ldy=%d", Cout, ldy);
     FEA_CHECK(((uintptr_t)y % 16 == 0) && ((uintptr_t)w_packed % 16 == 0) && ((uintptr_t)x % 4 == 0), FEA_E_BADARG, "fea_conv3x3_first: alignment");
     FEA_CHECK((long long)H * W * ldy < (1ll << 31) && (long long)C * H * W < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "fea_conv3x3_first: image too large");
+    {   // whole 8x32 tiles, 64 channels: the persistent kernel (its partial table has fea_conv3x3_first_rows() rows)
+        int rc = FEA_OK;
+        if (fea_first_conv_p(x, w_packed, bias, y, ldy, stats, 0, N, C, H, W, Cout, (hipStream_t)stream, &rc)) return rc;
+    }
     IgemmArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.stats = stats;
     a.ldx = 0; a.ldy = ldy; a.H = H; a.W = W; a.Cin = C; a.Cout = Cout; a.Cup = Cout;
@@ -1132,6 +1136,10 @@ extern "C" int fea_conv3x3_first_bias_relu(const float* x, const void* w_packed,
     FEA_CHECK(Cout > 0 && Cout % 64 == 0 && ldy >= Cout && ldy % 8 == 0, FEA_E_UNSUPPORTED_SHAPE, "%s: Cout=%d ldy=%d", who, Cout, ldy);
     FEA_CHECK(((uintptr_t)y % 16 == 0) && ((uintptr_t)w_packed % 16 == 0) && ((uintptr_t)x % 4 == 0), FEA_E_BADARG, "%s: alignment", who);
     FEA_CHECK((long long)H * W * ldy < (1ll << 31) && (long long)C * H * W < (1ll << 31), FEA_E_UNSUPPORTED_SHAPE, "%s: image too large", who);
+    {
+        int rc = FEA_OK;
+        if (fea_first_conv_p(x, w_packed, bias, y, ldy, nullptr, 1, N, C, H, W, Cout, (hipStream_t)stream, &rc)) return rc;
+    }
     IgemmArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.stats = nullptr;
     a.ldx = 0; a.ldy = ldy; a.H = H; a.W = W; a.Cin = C; a.Cout = Cout; a.Cup = Cout;

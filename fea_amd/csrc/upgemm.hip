@@ -45,6 +45,9 @@ struct UpgArgs {
 
 constexpr int U_REG = 32768;                   // one stage of one operand: 256 rows x 128 B
 constexpr int U_NST = 16;                      // 16-byte stores per wave and tile
+#ifndef U_NT_ST
+#define U_NT_ST 0
+#endif
 #ifndef U_PREFETCH
 #define U_PREFETCH 0       // 1: one discarded piece per wave and chunk pulls the next tile's first pixel rows into L2 (measured: no gain, see below)
 #endif
@@ -276,7 +279,11 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
                 const auto r0 = __builtin_amdgcn_permlane16_swap(lo0, lo1, false, false);
                 const auto r1 = __builtin_amdgcn_permlane16_swap(hi0, hi1, false, false);
                 const u32x4 out = {r0[0], r1[0], r0[1], r1[1]};
+#if U_NT_ST      // A/B: nontemporal output stores
+                __builtin_nontemporal_store(out, reinterpret_cast<u32x4*>(g.y + sbase + lane_off[j]));
+#else
                 *reinterpret_cast<u32x4*>(g.y + sbase + lane_off[j]) = out;
+#endif
             }
         }
     };

@@ -78,7 +78,9 @@ def _table_rows(N, h, w) -> int:
     """Upper bound of the rows of a conv kernel's partial-sum table (`stats` / `part`): one per pixel tile for the
     one-tile-per-workgroup kernels, two per workgroup (at most 2 x 256, at most 2 per tile) for the persistent ones."""
     nt = L.call("fea_conv_num_tiles", N, h, w)
-    return max(nt, min(512 * L.load().fea_get_persistent_split(), 2 * N * ((h + 7) // 8) * ((w + 31) // 32)))
+    split, t8 = L.load().fea_get_persistent_split(), N * ((h + 7) // 8) * ((w + 31) // 32)
+    # (the persistent first layer: one row per wave, three workgroups per CU)
+    return max(nt, min(512 * split, 2 * t8), min(3072 * split, 4 * t8))
 
 
 class _Plan:
@@ -556,6 +558,8 @@ class UNetEngine:
             bn = f"{blk}.{int(idx) + 1}"
             cf = pl.coef[name]
             if training:
+                if name == "enc1.0" and self.first_direct:
+                    rows_p = L.call("fea_conv3x3_first_rows", N, self.in_channels, h, w, cout, code)
                 ntiles = rows_p or L.call("fea_conv_num_tiles", N, h, w)
                 L.call("fea_bn_finalize", stats, ntiles, N * h * w, P[bn + ".weight"], P[bn + ".bias"],
                        B[bn + ".running_mean"], B[bn + ".running_var"], BN_MOMENTUM, BN_EPS,

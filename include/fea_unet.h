@@ -101,6 +101,10 @@ int fea_pack_batch(const void* jobs_dev, int njobs, int nblocks, int dtype, void
 int fea_pack_conv3x3_first(const float* w, void* out, int Co, int C, int dtype, void* stream);
 int fea_conv3x3_first(const float* x_nchw, const void* w_packed, const float* bias, void* y, int ldy, float* stats,
                       int N, int C, int H, int W, int Cout, int dtype, void* stream);
+/* Rows of the BatchNorm partial table `stats` that fea_conv3x3_first writes for this shape (same layer, models.py:28-29): with
+ * Cout = 64, H % 8 = 0 and W % 32 = 0 a persistent kernel serves the layer and writes one row per wave (<= 3,072 x the
+ * persistent split); 0 = one row per 256-pixel tile, fea_conv_num_tiles(). */
+int fea_conv3x3_first_rows(int N, int C, int H, int W, int Cout, int dtype);
 /* its weight gradient: dW[co,c,3,3] = sum_p dy[p,co] x[p+tap,c] from dy NHWC bf16 and x fp32 NCHW.
  * ws: fp32 workspace of fea_first_wgrad_ws_bytes() bytes. */
 size_t fea_first_wgrad_ws_bytes(int N, int H, int W, int Cout);

@@ -298,3 +298,44 @@ def test_config3_bf16_against_fp32_engine_at_full_size():
     if flips.any():
         assert float(ref["logits"][flips].abs().max()) < 0.25
     assert agree >= 0.98
+
+
+@pytest.mark.parametrize("cin,n,hw", [(3, 2, (512, 512)), (5, 2, (512, 384))])
+def test_first_layer_persistent_many_tiles_per_workgroup(cin, n, hw):
+    """fea_conv3x3_first on its persistent kernel (first_conv.hip) where a workgroup walks several tiles: the halo of the next
+    tile prefetched into registers, two LDS halo buffers, BatchNorm sums kept in registers across tiles and across image
+    borders.  Against F.conv2d on the CPU (Conv2d(in_channels, 64, 3, padding=1), models.py:28), and against the
+    one-tile-per-workgroup kernel (FEA_AMD_FIRST_P=0) on the same input."""
+    h, w = hw
+    co, code = 64, L.dt_code(BF)
+    rows = L.call("fea_conv3x3_first_rows", n, cin, h, w, co, code)
+    ntiles8 = n * (h // 8) * (w // 32)
+    assert rows > 0 and ntiles8 / (rows / 4) >= 2, (rows, ntiles8)
+    g = torch.Generator().manual_seed(43)
+    x = rnd(BF, n, cin, h, w, gen=g)
+    wt = (rnd(BF, co, cin, 3, 3, gen=g) / (3 * cin ** 0.5)).to(BF).float()
+    bias = torch.randn(co, generator=g)
+    ref = F.conv2d(x, wt, bias, padding=1)
+    wp = torch.empty((9 * cin + 31) // 32 * co * 32, dtype=BF, device=DEV)
+    L.call("fea_pack_conv3x3_first", wt.to(DEV), wp, co, cin, code, S())
+    xd = x.to(DEV).contiguous()
+    y = torch.full((n, h, w, co), float("nan"), dtype=BF, device=DEV)
+    stats = torch.full((rows, co, 2), float("nan"), device=DEV)
+    L.call("fea_conv3x3_first", xd, wp, bias.to(DEV), y, co, stats, n, cin, h, w, co, code, S())
+    torch.cuda.synchronize()
+    check(from_nhwc(y, co), ref, BF, "persistent first-layer conv")
+    s = stats.double().sum(0).cpu()
+    ref_s = torch.stack([ref.double().sum((0, 2, 3)), (ref.double() ** 2).sum((0, 2, 3))], 1)
+    assert rel_l2(s, ref_s) < 1e-5, "BN partial sums"
+    os.environ["FEA_AMD_FIRST_P"] = "0"
+    try:
+        assert L.call("fea_conv3x3_first_rows", n, cin, h, w, co, code) == 0
+        y0 = torch.full((n, h, w, co), float("nan"), dtype=BF, device=DEV)
+        st0 = torch.full((L.call("fea_conv_num_tiles", n, h, w), co, 2), float("nan"), device=DEV)
+        L.call("fea_conv3x3_first", xd, wp, bias.to(DEV), y0, co, st0, n, cin, h, w, co, code, S())
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["FEA_AMD_FIRST_P"]
+    # the same products in the same k order per output element, bias added at the start instead of the end: equal up to fp32 rounding
+    assert (y.float() - y0.float()).abs().max().item() <= 2 ** -6 * max(1.0, ref.abs().max().item())
+    assert rel_l2(s, st0.double().sum(0).cpu()) < 1e-6

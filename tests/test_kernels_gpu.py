@@ -305,7 +305,7 @@ def test_conv3x3_bias_relu_pool_inference_kernel(shape, pooled):
 
 
 @pytest.mark.parametrize("cin", [3, 1, 5, 7])
-@pytest.mark.parametrize("hw", [(32, 48), (16, 16), (40, 72)])
+@pytest.mark.parametrize("hw", [(32, 48), (16, 16), (40, 72), (32, 64), (8, 96)])      # the last two: whole 8x32 tiles, the persistent kernel
 def test_first_layer_direct_path(cin, hw):
     """enc1.0 = Conv2d(in_channels, 64, 3, padding=1) straight from the fp32 NCHW input (bf16
     path): forward + BN partial sums + weight gradient against F.conv2d on bf16-rounded inputs."""
@@ -320,7 +320,9 @@ def test_first_layer_direct_path(cin, hw):
     ks = (9 * cin + 31) // 32
     wp = torch.empty(ks * co * 32, dtype=dt, device=DEV)
     L.call("fea_pack_conv3x3_first", wt.to(DEV), wp, co, cin, code, S())
-    ntiles = L.call("fea_conv_num_tiles", n, h, w)
+    rows_p = L.call("fea_conv3x3_first_rows", n, cin, h, w, co, code)
+    assert (rows_p > 0) == (h % 8 == 0 and w % 32 == 0)
+    ntiles = rows_p or L.call("fea_conv_num_tiles", n, h, w)
     stats = torch.full((ntiles, co, 2), float("nan"), device=DEV)
     y = torch.full((n, h, w, co + 64), float("nan"), dtype=dt, device=DEV)
     xd = x.to(DEV).contiguous()
