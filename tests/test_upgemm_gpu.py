@@ -73,3 +73,31 @@ def test_upconv_fwd_persistent_gemm(case):
     # both paths accumulate the same products in fp32 (different order) and round once to bf16
     d = (outs[0].float() - outs[1].float()).abs().max().item()
     assert d <= 2 ** -6 * max(1.0, ref.abs().max().item()), d
+
+
+def test_upconv_fwd_persistent_gemm_slice_input_no_bias_and_split():
+    """x as a channel slice of a wider buffer (ldx > Cin), no bias, and the persistent work split of the data-parallel trainer
+    (fea_set_persistent_split(4): four times the walkers, a quarter of the tile range each)."""
+    n, h, w, ci, co = 4, 32, 64, 128, 64
+    g = torch.Generator().manual_seed(8)
+    code = L.dt_code(BF)
+    x = rnd(BF, n, ci, h, w, gen=g)
+    wt = (torch.randn(ci, co, 2, 2, generator=g) / ci ** 0.5).to(BF).float()
+    ref = F.conv_transpose2d(x, wt, None, stride=2)
+    wp = torch.empty(4 * ci * co, dtype=BF, device=DEV)
+    L.call("fea_pack_upconv2x2", wt.to(DEV), wp, ci, co, 0, code, S())
+    wide = torch.full((n, h, w, ci + 64), float("nan"), dtype=BF, device=DEV)
+    wide[..., 64:] = to_nhwc(x, BF)
+    xs = wide.data_ptr() + 64 * 2
+    lib = L.load()
+    old = lib.fea_get_persistent_split()
+    try:
+        for split in (1, 4):
+            assert lib.fea_set_persistent_split(split) == 0
+            y = torch.full((n, 2 * h, 2 * w, co), float("nan"), dtype=BF, device=DEV)
+            with _env(FEA_AMD_UPGEMM=1, FEA_AMD_UPG_WALKERS=None):
+                L.call("fea_upconv2x2_fwd", xs, ci + 64, wp, None, y, co, n, h, w, ci, co, code, S())
+            torch.cuda.synchronize()
+            check(from_nhwc(y, co), ref, BF, f"upconv fwd, sliced input, split {split}")
+    finally:
+        lib.fea_set_persistent_split(old)
