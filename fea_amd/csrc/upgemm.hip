@@ -166,6 +166,7 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
     // hold it (as persistent registers, or as the C operand of a tile's first MFMAs, it spilled the kernel)
     float* const blds = reinterpret_cast<float*>(smem + 4 * U_REG);
     if (tid < 256) blds[tid] = g.bias ? g.bias[(nt * 256 + tid) % g.Cup] : 0.f;
+    __syncthreads();           // (with its fence, before the first LDS-DMA piece: the bare s_barrier of the loop orders nothing for the compiler)
     // output: lane = pixel r16 of accumulator tile m, 8 channels from chl of the 32-column pair j
     const int chl = (q16 & 1) * 16 + (q16 >> 1) * 8;
     int lane_off[2];
