@@ -250,6 +250,9 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     // inline asm in a fixed order (the LDS returns them in order) retired by a constant counted wait, lgkmcnt(7).
     // `between(step)` is called once per k-step behind its MFMAs (the LDS-DMA pieces of the next stage go there).
     auto lds_rd = [&](u32x4& dst, uint32_t addr, auto offc) {
+#ifdef C3P_EXP_HALF_READS      // EXPERIMENT (wrong results): every second fragment read dropped = what a wave tile with half the reads per MFMA could gain
+        if constexpr ((decltype(offc)::value & 2048) != 0) return;
+#endif
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(offc)::value) : "memory");
     };
     auto mma_stage = [&](auto cc, auto sc_, auto&& hook) {
