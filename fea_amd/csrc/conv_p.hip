@@ -250,7 +250,11 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     // inline asm in a fixed order (the LDS returns them in order) retired by a constant counted wait, lgkmcnt(7).
     // `between(step)` is called once per k-step behind its MFMAs (the LDS-DMA pieces of the next stage go there).
     auto lds_rd = [&](u32x4& dst, uint32_t addr, auto offc) {
-#ifdef C3P_EXP_HALF_READS      // EXPERIMENT (wrong results): every second fragment read dropped = what a wave tile with half the reads per MFMA could gain
+#ifdef C3P_EXP_HALF_READS      // EXPERIMENT (wrong results): every second fragment read dropped.  17-28 % faster -- but NOT what a wave tile with
+        // half the reads per MFMA gains: that was built (64 pixels x 64 channels per wave, 288 weight registers, each fragment feeding
+        // four MFMAs) and measured 1-3 % (and spilled with the BatchNorm sums), and dropping every fragment WAIT instead
+        // (C3P_EXP_NO_WAITS) changes nothing.  The MFMAs of the dropped fragments multiply the same stale registers every time:
+        // operands that do not toggle draw less power, and the chip, clock-limited by its power budget under this load, runs faster.
         if constexpr ((decltype(offc)::value & 2048) != 0) return;
 #endif
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(offc)::value) : "memory");
@@ -461,7 +465,9 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
                 if constexpr ((mm & (P_WAIT_EVERY_OVL - 1)) == 0) {
                     // fragments mm .. mm + P_WAIT_EVERY_OVL - 1: 8 ring reads are in flight (10 in k-steps 16 / 17, where the next half's two
                     // bias reads sit between them), the oldest ones are needed (never fewer in flight: no tail)
+#ifndef C3P_EXP_NO_WAITS       // EXPERIMENT (racy): no fragment waits = what LDS latency beyond the ring's reach costs (measured: nothing)
                     asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"((step >= 16 ? 10 : 8) - P_WAIT_EVERY_OVL) : "memory");
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
