@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ shift, const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, const float* __restrict__ coef,
                                                           T* __restrict__ dy, float* __restrict__ part,
-                                                          int N, int H, int W, int C, long long items_per_block) {
+                                                          int N, int H, int W, int C, long long items_per_block, int rows_bound) {
     constexpr int V = Vec<T>::N;
     const int gpp = C / V;                       // host guarantees gpp <= 256 and 256 % gpp == 0
     const int slots = 256 / gpp;
@@ -541,6 +541,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const T* __restrict__ 
         float* dst = part + ((long long)blockIdx.x * C + threadIdx.x * V) * 2;
 #pragma unroll
         for (int j = 0; j < V; ++j) { dst[2 * j] = s0[j]; dst[2 * j + 1] = s1[j]; }
+        // the caller sized the table for rows_bound rows (fea_bn_bwd_blocks) and reduces that many: the rows no block owns are
+        // zeroed here, dealt over the blocks (was a hipMemsetAsync in front of every launch: one more small launch, 22 per step)
+        for (int r = gridDim.x + blockIdx.x; r < rows_bound; r += gridDim.x) {
+            float* z = part + ((long long)r * C + threadIdx.x * V) * 2;
+#pragma unroll
+            for (int j = 0; j < 2 * V; ++j) z[j] = 0.f;
+        }
     }
 }
 
@@ -796,14 +803,10 @@ static int bn_bwd_launch(bool apply, const void* da_full, int ld_da, const void*
     long long ipb = (nitems + nblk - 1) / nblk;
     ipb = (ipb + slots - 1) / slots * slots;
     hipStream_t s = (hipStream_t)stream;
-    // zero the rows of `part` that no block writes (nblk may be < the bound the caller sized for)
+    // the rows of `part` that no block writes (nblk may be < the bound the caller sized for) are zeroed by the kernel itself
     const int bound = fea_bn_bwd_blocks(N, H, W, C);
-    if (bound > nblk) {
-        hipError_t e = hipMemsetAsync(part + (long long)nblk * C * 2, 0, (size_t)(bound - nblk) * C * 2 * sizeof(float), s);
-        FEA_CHECK(e == hipSuccess, FEA_E_LAUNCH, "%s: memset failed", who);
-    }
 #define BNB(POOLV, APPLYV) hipLaunchKernelGGL((bn_relu_bwd_kernel<T, POOLV, APPLYV>), dim3(nblk), dim3(256), 0, s, (const T*)da_full, ld_da, \
-        (const T*)dpool, (const T*)y, scale, shift, save_mean, save_invstd, coef, (T*)dy, part, N, H, W, C, ipb)
+        (const T*)dpool, (const T*)y, scale, shift, save_mean, save_invstd, coef, (T*)dy, part, N, H, W, C, ipb, bound)
     DT_SWITCH(dtype, who,
               if (pool) { if (apply) BNB(true, true); else BNB(true, false); }
               else      { if (apply) BNB(false, true); else BNB(false, false); });
