@@ -85,6 +85,9 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 #ifndef P_WAIT_EVERY
 #define P_WAIT_EVERY 4
 #endif
+#ifndef P_OVL2
+#define P_OVL2 1        // 0: the K = 1152 layers run item() (epilogue behind the MFMAs, not between them): A/B builds
+#endif
 #ifndef P_WAIT_EVERY_OVL
 #define P_WAIT_EVERY_OVL 4
 #endif
@@ -599,6 +602,113 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
         advance(ni, tx, ty);
     };
 
+    // ---- overlapped form for K = 1152 (OVL2: forward and plain data gradient of the 128-input-channel layers) ----------------
+    // Phases of a tile: (chunk 0, half A) (chunk 0, half B) (chunk 1, half A) (chunk 1, half B), chunk c in stage c.  Both halves'
+    // accumulators stay live through the tile as before; what moves is the epilogue: half A's runs between the MFMA pairs of the
+    // fourth phase, half B's between those of the NEXT tile's first phase (item() left the matrix pipe idle for ~1,660 of a tile's
+    // ~12,900 cycles, scripts/c3p_stamps.py).  LDS-DMA: this tile's chunk 1 goes to stage 1 during the first phase (stage 1 was last
+    // read before the previous tile's barrier), the next tile's chunk 0 to stage 0 during the third (stage 0 was last read before
+    // this tile's first barrier); the two barriers sit in front of k-step 16 of the second and the fourth phase, where the ring
+    // starts reading the other stage.  The bias is the C operand of both halves' first k-step of chunk 0.
+    constexpr bool OVL2 = P_OVL2 && NCH == 2 && EPI == 0;
+    auto mma_phase = [&](auto pc, auto&& hook, auto&& before16) {
+        constexpr int P = decltype(pc)::value, C = P >> 1, HALF = P & 1, STG = C;
+        constexpr int NP = (P + 1) & 3, NSTG = NP >> 1, NHALF = NP & 1;
+        constexpr bool BIAS = C == 0, NBIAS = NSTG == 0;
+        constexpr int CW = NCH == 2 ? C : 0;
+        const uint32_t st = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        f32x4 biasv[2];
+        if constexpr (BIAS) {
+            // on entry: 2 bias reads, then the 8 reads of k-steps 0 and 1 are in flight
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bqr[0]), "+v"(bqr[1]));
+            biasv[0] = __builtin_bit_cast(f32x4, bqr[0]); biasv[1] = __builtin_bit_cast(f32x4, bqr[1]);
+        }
+        sfor<0, 18>([&](auto stc) {
+            constexpr int step = decltype(stc)::value, tap = step >> 1, ks = step & 1;
+            constexpr int nstep = step + 2, ntap = nstep >> 1, nks = nstep & 1, ndy = ntap / 3, ndx = ntap % 3;
+            if constexpr (step == 16) { before16(); if constexpr (NBIAS) prime_bias(); }
+            sfor<0, 4>([&](auto mc) {
+                constexpr int mm = decltype(mc)::value, m = HALF * 4 + mm, ai = (step & 1) * 4 + mm;
+                if constexpr ((mm & (P_WAIT_EVERY_OVL - 1)) == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"((step >= 16 && NBIAS ? 10 : 8) - P_WAIT_EVERY_OVL) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wf[CW][tap][ks][n]),
+                                                                        __builtin_bit_cast(bf16x8, Ar[ai]),
+                                                                        (BIAS && step == 0) ? biasv[n] : acc[m][n], 0, 0, 0);
+                if constexpr (nstep < 18)
+                    lds_rd(Ar[ai], st + (abase[(m >> 1) + ndy][ndx] ^ (uint32_t)(nks << 6)),
+                           std::integral_constant<int, STG * P_STAGE + (m & 1) * 2048>{});
+                else
+                    prime_reads(std::integral_constant<int, NSTG>{}, std::integral_constant<int, NHALF>{},
+                                std::integral_constant<int, nstep - 18>{}, mc);
+                hook(std::integral_constant<int, step * 4 + mm>{});
+            });
+        });
+    };
+    auto item_ovl2 = [&](int t, auto fc) {
+        constexpr bool FIRST = decltype(fc)::value;       // no previous tile: no second-half epilogue to interleave
+        pin_weights();
+        if constexpr (FIRST) {
+            __builtin_amdgcn_s_barrier();                 // chunk 0 of the first tile (prologue) has landed for every wave
+            prime_bias();
+            sfor<0, 8>([&](auto ic) {
+                prime_reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, (decltype(ic)::value >> 2)>{},
+                            std::integral_constant<int, (decltype(ic)::value & 3)>{});
+            });
+        }
+        int n2 = ni, x2 = tx, y2 = ty;
+        advance(n2, x2, y2);
+        const bool more = t + 1 < t1;
+        const __amdgpu_buffer_rsrc_t crs = tile_rsrc(ni);
+        const int ctoff = tile_off(tx, ty, 1);
+        const unsigned cedge = tile_edge(tx, ty);
+        const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(more ? n2 : ni);
+        const int ntoff = tile_off(x2, y2, 0);
+        const unsigned nedge = more ? tile_edge(x2, y2) : 63u;          // nothing follows: zeros land, no lane reads memory
+        __bf16* const yt = g.y + (long long)ni * g.y_img_stride + ((long long)(ty * P_TH) * W + tx * P_TW) * g.ldy + y_lane;
+        // (chunk 0, A): this tile's chunk 1 -> stage 1 behind slots 1, 3, .. 21; from slot 24 on the previous tile's half-B epilogue
+        mma_phase(std::integral_constant<int, 0>{}, [&](auto slotc) {
+            constexpr int slot = decltype(slotc)::value;
+            if constexpr ((slot & 1) == 1 && (slot >> 1) < P_NDMA) issue_piece(crs, ctoff, cedge, 1, std::integral_constant<int, (slot >> 1)>{});
+            if constexpr (!FIRST) epi_slot(prev_yt, std::integral_constant<int, 1>{}, std::integral_constant<int, 24>{}, slotc);
+        }, [] {});
+        // (chunk 0, B): in front of k-step 16 the pieces of chunk 1 have landed (behind them only the 4 stores of that epilogue) and
+        // every read of stage 0 has completed; after the barrier stage 1 is read and stage 0 may be overwritten
+        mma_phase(std::integral_constant<int, 1>{}, [](auto) {}, [&] {
+            if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else                 asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        });
+        // (chunk 1, A): the next tile's chunk 0 -> stage 0
+        mma_phase(std::integral_constant<int, 2>{}, [&](auto slotc) {
+            constexpr int slot = decltype(slotc)::value;
+            if constexpr ((slot & 1) == 1 && (slot >> 1) < P_NDMA) issue_piece(nrs, ntoff, nedge, 0, std::integral_constant<int, (slot >> 1)>{});
+        }, [] {});
+        // (chunk 1, B): this tile's half-A epilogue from slot 8 on; the tile's second barrier in front of k-step 16 (behind the
+        // next tile's pieces only the NSTB stores issued since)
+        mma_phase(std::integral_constant<int, 3>{}, [&](auto slotc) {
+            epi_slot(yt, std::integral_constant<int, 0>{}, std::integral_constant<int, S0B>{}, slotc);
+        }, [&] {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NSTB) : "memory");
+            __builtin_amdgcn_s_barrier();
+        });
+        prev_yt = yt;
+        advance(ni, tx, ty);
+    };
+
+    if constexpr (OVL2) {
+        if (t0 < t1) {
+            item_ovl2(t0, std::true_type{});
+            for (int t = t0 + 1; t < t1; ++t) item_ovl2(t, std::false_type{});
+            sfor<0, 4 * NPER>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                epi_micro(prev_yt, std::integral_constant<int, 4 + k / NPER>{}, std::integral_constant<int, k % NPER>{});
+            });
+        }
+    } else
     if constexpr (OVL) {
         if (t0 < t1) {
             item_ovl(t0, std::integral_constant<int, 0>{}, std::true_type{});

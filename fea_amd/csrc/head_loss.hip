@@ -933,11 +933,17 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
     // (On the VALU -- 16 channels x <= 8 classes of fmas per lane and tile, 96 accumulators -- this was 40 % of the kernel's
     // instructions and kept the BatchNorm-backward mode from fitting two waves per SIMD.)
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
-    __shared__ __attribute__((aligned(128))) char tsp[GW ? 4 : 1][3072];     // per wave: [16 px][128 B] activations, [16 classes][16 px] fp32 d
+    // Bank layout (round 3: SQ_LDS_BANK_CONFLICT was 77 % of this kernel's LDS cycles, the LDS busy for half of its time, with pixel
+    // rows 128 B apart: every row began at bank 0).  Rows are APITCH = 160 B apart: the four rows x 32 B a 16-lane group of the
+    // transposing read touches cover all 32 banks once, the eight rows of a ds_write_b128 group meet two by two (an XOR swizzle
+    // that clears both costs the kernel a register it does not have: 256, one spilled).  The d table's rows are 20 floats apart,
+    // so the eight lanes of its 16-byte reads cover all banks too.
+    constexpr int APITCH = 160, DTP = 20;
+    __shared__ __attribute__((aligned(128))) char tsp[GW ? 4 : 1][16 * APITCH + 16 * DTP * 4];     // per wave: [16 px][APITCH] activations, [16 classes][DTP] fp32 d
     char* const my = tsp[GW ? wv : 0];
-    float* const dt = reinterpret_cast<float*>(my + 2048);
+    float* const dt = reinterpret_cast<float*>(my + 16 * APITCH);
     if constexpr (GW) {
-        for (int i = lane; i < 256; i += 64) dt[i] = 0.f;             // rows of absent classes stay zero
+        for (int i = lane; i < 16 * DTP; i += 64) dt[i] = 0.f;        // rows of absent classes stay zero
     }
     f32x4 G[4];
     float gb[NE];
@@ -1021,18 +1027,18 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
         dp += dstep;
         if constexpr (!GW) return;
         // dW (see above): lane (pixel r16, q) writes its 16 activations and its dlogits, then reads the transposed operands
-        *reinterpret_cast<u32x4*>(my + r16 * 128 + q * 16) = x0;
-        *reinterpret_cast<u32x4*>(my + r16 * 128 + 64 + q * 16) = x1;
+        *reinterpret_cast<u32x4*>(my + r16 * APITCH + q * 16) = x0;
+        *reinterpret_cast<u32x4*>(my + r16 * APITCH + 64 + q * 16) = x1;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) dt[(q + 4 * e) * 16 + r16] = d[e];
+        for (int e = 0; e < NE; ++e) dt[(q + 4 * e) * DTP + r16] = d[e];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // B: lane (class n = r16, k-group q): d[pixel 8q .. 8q+7][n] for q < 2, zeros for the padding k-slots
         float dv[8];
         {
-            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(dt + r16 * 16 + (q & 1) * 8);
-            const f32x4 hi4 = *reinterpret_cast<const f32x4*>(dt + r16 * 16 + (q & 1) * 8 + 4);
+            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(dt + r16 * DTP + (q & 1) * 8);
+            const f32x4 hi4 = *reinterpret_cast<const f32x4*>(dt + r16 * DTP + (q & 1) * 8 + 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { dv[j] = q < 2 ? lo4[j] : 0.f; dv[4 + j] = q < 2 ? hi4[j] : 0.f; }
         }
@@ -1047,7 +1053,7 @@ __global__ __launch_bounds__(256, 2) void head_loss_bwd_mfma_kernel(const __bf16
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 h2[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (lds_s16x4_t*)(my + (8 * (q & 1) + 4 * u + (r16 >> 2)) * 128 + (16 * t + 4 * (r16 & 3)) * 2));
+                    (lds_s16x4_t*)(my + (8 * (q & 1) + 4 * u + (r16 >> 2)) * APITCH + (16 * t + 4 * (r16 & 3)) * 2));
             const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
             G[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, dbh), G[t], 0, 0, 0);
             G[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, dbl), G[t], 0, 0, 0);
