@@ -2,9 +2,10 @@
 //
 // The layer is one output store (2 bytes per pixel and channel against 4 C / 64 of input): igemm.hip's MODE 3 runs it as one
 // 256-pixel tile per workgroup -- halo load, LDS, im2col gather, 16 MFMAs, staged store, every latency in a row, four workgroups per
-// CU to hide them: 0.74 ms at batch 64 x 512^2 on random data where the store alone would take 0.36.  Here a workgroup walks a
-// range of 8x32-pixel tiles (0.66 ms; with three of every four stores removed 0.31 ms, with the gather removed 0.66: what is left
-// is the store stream itself, 3.5 TB/s from the 12 waves a CU holds where the one-thread-per-16-bytes BatchNorm pass writes at 6):
+// CU to hide them: 0.74 ms at batch 64 x 512^2 on random data.  Here a workgroup walks a range of 8x32-pixel tiles: 0.62 ms.
+// That is 3.4 TB/s of stores where a store-only kernel of the same tile shape and lane pattern reaches 4.5-5.7
+// (scripts/hbm_tile_probe.hip): with three of every four stores removed the kernel takes 0.31 ms, with the gather removed
+// 0.62 -- the gather / MFMA part and the store stream add up instead of overlapping (open).
 //   * the NEXT tile's fp32 halo (C x 10 x 34) travels global -> registers while this tile is multiplied, and goes to the other
 //     of two LDS halo buffers behind one barrier per tile;
 //   * a wave owns 64 pixels x 64 channels, two 32-pixel halves in turn;
