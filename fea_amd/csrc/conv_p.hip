@@ -38,6 +38,7 @@ struct C3pArgs {
     int H, W;
     int CoutTot;                              // GEMM N of the packed weight
     int tiles_x, tiles_y, ntiles, tiles_per_wg, npixwg, nhalf;
+    int wsx, wsn;                             // WALK kernels: the cursor's stride in (x, image)
     // EPI 2
     const __bf16* ybn; int ldybn; long long ybn_img_stride;
     const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
@@ -95,7 +96,7 @@ __device__ __forceinline__ void st_out(__bf16* p, const u32x4& v) {
     if constexpr (P_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
     else *reinterpret_cast<u32x4*>(p) = v;
 }
-template <int NCH, int EPI, int STATS>
+template <int NCH, int EPI, int STATS, bool WALK = false>
 __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     // OVL (K = 576): a tile is multiplied as two pixel halves (accumulator tiles m = 0..3, then 4..7, 18 k-steps each);
     // the epilogue of one half is issued, a micro-operation or two at a time, between the MFMA pairs of the other half
@@ -305,11 +306,19 @@ __global__ __launch_bounds__(256, 1) void c3p_kernel(const C3pArgs g) {
     };
 
     // ---- tile walk ----------------------------------------------------------------------------------------
-    const int t0 = pw * g.tiles_per_wg;
-    const int t1 = min(t0 + g.tiles_per_wg, g.ntiles);
-    int ty = t0 % g.tiles_y, tx = (t0 / g.tiles_y) % g.tiles_x, ni = t0 / (g.tiles_y * g.tiles_x);
+    // WALK false: workgroup pw takes tiles pw * tiles_per_wg ..., consecutive (vertical neighbours one after the other: the two shared
+    // halo rows are L2 hits).  WALK true (64 -> 64 layers, which are HBM-bound; needs npixwg % tiles_y == 0): tiles pw, pw + npixwg,
+    // ... -- at any moment the chip writes one compact window of npixwg tiles instead of npixwg windows 8 MB apart.  A store-only
+    // probe of this tile shape writes 10 % faster that way (scripts/hbm_tile_probe.hip); the 64 -> 64 launches @512^2 went
+    // 1.07 -> 0.96 ms (forward) and 1.42 -> 1.30 ms (data gradient with the fused reduction), the 64 -> 128 ones did not move.
+    // The cursor keeps its tile row and advances by (wsx, wsn) in (x, image); t counts the workgroup's own tiles.
+    const int first = WALK ? pw : pw * g.tiles_per_wg;
+    const int t0 = WALK ? 0 : first;
+    const int t1 = WALK ? (first < g.ntiles ? (g.ntiles - first + g.npixwg - 1) / g.npixwg : 0) : min(first + g.tiles_per_wg, g.ntiles);
+    int ty = first % g.tiles_y, tx = (first / g.tiles_y) % g.tiles_x, ni = first / (g.tiles_y * g.tiles_x);
     auto advance = [&](int& n_, int& x_, int& y_) {
-        if (++y_ == g.tiles_y) { y_ = 0; if (++x_ == g.tiles_x) { x_ = 0; ++n_; } }
+        if constexpr (WALK) { x_ += g.wsx; if (x_ >= g.tiles_x) { x_ -= g.tiles_x; ++n_; } n_ += g.wsn; }
+        else if (++y_ == g.tiles_y) { y_ = 0; if (++x_ == g.tiles_x) { x_ = 0; ++n_; } }
     };
     if (t0 < t1) issue(ni, tx, ty, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -819,6 +828,13 @@ static void c3p_fill(C3pArgs& a, const C3pPlan& p, const void* x, int ldx, const
     a.x_img_stride = (long long)H * W * ldx; a.y_img_stride = (long long)H * W * ldy;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_wg = p.tiles_per_wg;
     a.npixwg = p.npixwg; a.nhalf = p.nhalf;
+    a.wsx = (p.npixwg / p.tiles_y) % p.tiles_x; a.wsn = p.npixwg / (p.tiles_y * p.tiles_x);
+}
+
+// the interleaved tile walk (c3p_kernel's WALK): the 64 -> 64 layers on whole-column strides.  FEA_AMD_P_WALK=0 switches it off (A/B runs).
+static bool c3p_walk(const C3pPlan& p, int Cin, int Cout) {
+    static const bool off = getenv("FEA_AMD_P_WALK") && getenv("FEA_AMD_P_WALK")[0] == '0';
+    return !off && Cin == 64 && Cout == 64 && p.npixwg % p.tiles_y == 0;
 }
 
 extern "C" int fea_conv3x3p(const void* x, int ldx, const void* w_frag, const float* bias, void* y, int ldy, float* stats,
@@ -835,9 +851,10 @@ extern "C" int fea_conv3x3p(const void* x, int ldx, const void* w_frag, const fl
     dim3 grid((unsigned)(p.npixwg * p.nhalf)), block(256);
     // forward (bias given): sum y and sum y^2; data gradient (no bias): sum only (the ConvTranspose2d bias gradient)
     const int st = !stats ? 0 : (bias ? 2 : 1);
-#define C3P_LAUNCH(NCHV, STV) hipLaunchKernelGGL((c3p_kernel<NCHV, 0, STV>), grid, block, 0, (hipStream_t)stream, a)
-    if (Cin == 64) { if (st == 2) C3P_LAUNCH(1, 2); else if (st == 1) C3P_LAUNCH(1, 1); else C3P_LAUNCH(1, 0); }
-    else           { if (st == 2) C3P_LAUNCH(2, 2); else if (st == 1) C3P_LAUNCH(2, 1); else C3P_LAUNCH(2, 0); }
+#define C3P_LAUNCH(NCHV, STV, WV) hipLaunchKernelGGL((c3p_kernel<NCHV, 0, STV, WV>), grid, block, 0, (hipStream_t)stream, a)
+    if (c3p_walk(p, Cin, Cout)) { if (st == 2) C3P_LAUNCH(1, 2, true); else if (st == 1) C3P_LAUNCH(1, 1, true); else C3P_LAUNCH(1, 0, true); }
+    else if (Cin == 64) { if (st == 2) C3P_LAUNCH(1, 2, false); else if (st == 1) C3P_LAUNCH(1, 1, false); else C3P_LAUNCH(1, 0, false); }
+    else                { if (st == 2) C3P_LAUNCH(2, 2, false); else if (st == 1) C3P_LAUNCH(2, 1, false); else C3P_LAUNCH(2, 0, false); }
 #undef C3P_LAUNCH
     FEA_LAUNCH_CHECK();
     return FEA_OK;
@@ -858,8 +875,9 @@ extern "C" int fea_conv3x3p_dgrad_bnred(const void* dy, int lddy, const void* w_
     a.ybn = (const __bf16*)y; a.ldybn = ldy_bn; a.ybn_img_stride = (long long)H * W * ldy_bn;
     a.bn_scale = scale; a.bn_shift = shift; a.bn_mean = save_mean; a.bn_invstd = save_invstd; a.red_part = part;
     dim3 grid((unsigned)(p.npixwg * p.nhalf)), block(256);
-    if (Cin == 64) hipLaunchKernelGGL((c3p_kernel<1, 2, 0>), grid, block, 0, (hipStream_t)stream, a);
-    else           hipLaunchKernelGGL((c3p_kernel<2, 2, 0>), grid, block, 0, (hipStream_t)stream, a);
+    if (c3p_walk(p, Cin, Cout)) hipLaunchKernelGGL((c3p_kernel<1, 2, 0, true>), grid, block, 0, (hipStream_t)stream, a);
+    else if (Cin == 64) hipLaunchKernelGGL((c3p_kernel<1, 2, 0>), grid, block, 0, (hipStream_t)stream, a);
+    else                hipLaunchKernelGGL((c3p_kernel<2, 2, 0>), grid, block, 0, (hipStream_t)stream, a);
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }
@@ -877,8 +895,9 @@ extern "C" int fea_conv3x3p_bias_relu(const void* x, int ldx, const void* w_frag
     c3p_fill(a, p, x, ldx, w_frag, y, ldy, H, W, Cout);
     a.bias = bias; a.pool = (__bf16*)pool; a.ldpool = ldpool; a.pool_img_stride = (long long)(H / 2) * (W / 2) * ldpool;
     dim3 grid((unsigned)(p.npixwg * p.nhalf)), block(256);
-    if (Cin == 64) hipLaunchKernelGGL((c3p_kernel<1, 3, 0>), grid, block, 0, (hipStream_t)stream, a);
-    else           hipLaunchKernelGGL((c3p_kernel<2, 3, 0>), grid, block, 0, (hipStream_t)stream, a);
+    if (c3p_walk(p, Cin, Cout)) hipLaunchKernelGGL((c3p_kernel<1, 3, 0, true>), grid, block, 0, (hipStream_t)stream, a);
+    else if (Cin == 64) hipLaunchKernelGGL((c3p_kernel<1, 3, 0>), grid, block, 0, (hipStream_t)stream, a);
+    else                hipLaunchKernelGGL((c3p_kernel<2, 3, 0>), grid, block, 0, (hipStream_t)stream, a);
     FEA_LAUNCH_CHECK();
     return FEA_OK;
 }

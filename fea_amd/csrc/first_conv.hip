@@ -24,6 +24,8 @@ struct FcArgs {
     const float* x; const __bf16* w; const float* bias; __bf16* y; float* stats;
     int ldy, C, H, W;
     int tiles_x, tiles_y, ntiles, tiles_per_wg;
+    int walk, wsx, wsn;                 // walk = 1: workgroup b takes tiles b, b + gridDim.x, ... (the cursor keeps its tile row: stride (wsx, wsn) in (x, image))
+    unsigned long long* dbg;            // FC_STAMPS builds only: per-wave phase cycle sums (scripts/fc_stamps.py)
 };
 
 constexpr int FC_TH = 8, FC_TW = 32, FC_HW2 = FC_TW + 2, FC_HALO = (FC_TH + 2) * FC_HW2;       // 340 halo pixels per channel
@@ -58,8 +60,16 @@ __global__ __launch_bounds__(256, KS == 1 ? 3 : 2) void first_conv_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q16 = lane >> 4;
     const int C = g.C, H = g.H, W = g.W;
-    const int t0 = blockIdx.x * g.tiles_per_wg, t1 = min(t0 + g.tiles_per_wg, g.ntiles);
+    // tile walk: consecutive tiles, or (walk) every gridDim.x-th tile -- the chip then writes one compact window of gridDim.x tiles
+    // at any moment, which the store stream likes better (conv_p.hip, scripts/hbm_tile_probe.hip); t counts this workgroup's tiles
+    const int first = g.walk ? (int)blockIdx.x : (int)blockIdx.x * g.tiles_per_wg;
+    const int t0 = 0;
+    const int t1 = first >= g.ntiles ? 0 : g.walk ? (g.ntiles - first + (int)gridDim.x - 1) / (int)gridDim.x : min(g.tiles_per_wg, g.ntiles - first);
     if (t0 >= t1) return;
+    auto advance = [&](int& n_, int& x_, int& y_) {
+        if (g.walk) { x_ += g.wsx; if (x_ >= g.tiles_x) { x_ -= g.tiles_x; ++n_; } n_ += g.wsn; }
+        else if (++y_ == g.tiles_y) { y_ = 0; if (++x_ == g.tiles_x) { x_ = 0; ++n_; } }
+    };
 
     // packed weights [ks][co/16][lane][8]: the fragment of (k-step, 16-channel tile) is this lane's 16 bytes
     u32x4 Wf[KS][4];
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(256, KS == 1 ? 3 : 2) void first_conv_kernel(const 
         hedge |= (unsigned long long)((hy == 0 ? 1u : 0u) | (hy == FC_TH + 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == FC_TW + 1 ? 8u : 0u)) << (4 * i);
     }
     float hv[FC_AHEAD][HIT];
-    int ty = t0 % g.tiles_y, tx = (t0 / g.tiles_y) % g.tiles_x, ni = t0 / (g.tiles_y * g.tiles_x);
+    int ty = first % g.tiles_y, tx = (first / g.tiles_y) % g.tiles_x, ni = first / (g.tiles_y * g.tiles_x);
     int fy = ty, fx = tx, fn = ni;          // the fetch cursor runs FC_AHEAD tiles in front
     auto fetch = [&](auto slotc) {
         constexpr int slot = decltype(slotc)::value;
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(256, KS == 1 ? 3 : 2) void first_conv_kernel(const 
             const bool ok = hoff[i] != NONE && (((unsigned)(hedge >> (4 * i)) & edge) == 0);       // zero padding outside the image
             hv[slot][i] = ok ? xin[hoff[i]] : 0.f;
         }
-        if (++fy == g.tiles_y) { fy = 0; if (++fx == g.tiles_x) { fx = 0; ++fn; } }
+        advance(fn, fx, fy);
     };
     sfor<0, FC_AHEAD>([&](auto dc) { if (t0 + decltype(dc)::value < t1) fetch(dc); });
 
@@ -115,6 +125,12 @@ __global__ __launch_bounds__(256, KS == 1 ? 3 : 2) void first_conv_kernel(const 
     for (int n = 0; n < 4; ++n) { S[n] = f32x4{0.f, 0.f, 0.f, 0.f}; Q[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const int chl = (q16 & 1) * 16 + (q16 >> 1) * 8;
 
+#ifdef FC_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define FC_STAMP(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[k] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define FC_STAMP(k) do {} while (0)
+#endif
     for (int tb = t0; tb < t1; tb += FC_AHEAD)
     sfor<0, FC_AHEAD>([&](auto dc) {
         constexpr int slot = decltype(dc)::value;
@@ -124,8 +140,11 @@ __global__ __launch_bounds__(256, KS == 1 ? 3 : 2) void first_conv_kernel(const 
 #pragma unroll
         for (int i = 0; i < HIT; ++i)
             if (tid + i * 256 < HBUF) hb[tid + i * 256] = hv[slot][i];
-        __syncthreads();             // this tile's halo is complete; every wave has left the tile before the previous one (the other buffer)
+        FC_STAMP(0);                 // wait for the prefetched halo + LDS write
+        __syncthreads();
+        FC_STAMP(1);                 // barrier             // this tile's halo is complete; every wave has left the tile before the previous one (the other buffer)
         if (t + FC_AHEAD < t1) fetch(dc);          // in flight behind the next FC_AHEAD tiles' gathers, MFMAs and stores
+        FC_STAMP(2);                 // issue of the next halo
         __bf16* const yt = g.y + (((long long)ni * H + ty * FC_TH) * W + tx * FC_TW) * g.ldy;
 #pragma unroll 1
         for (int mh = 0; mh < 2; ++mh) {          // the wave's tile rows 2 wave + mh: two 16-pixel tiles each (rolled: registers)
@@ -174,8 +193,12 @@ __global__ __launch_bounds__(256, KS == 1 ? 3 : 2) void first_conv_kernel(const 
                 }
             }
         }
-        if (++ty == g.tiles_y) { ty = 0; if (++tx == g.tiles_x) { tx = 0; ++ni; } }
+        FC_STAMP(3);                 // gathers, MFMAs, epilogue and stores of both halves
+        advance(ni, tx, ty);
     });
+#ifdef FC_STAMPS
+    if (lane == 0 && g.dbg) for (int k = 0; k < 6; ++k) g.dbg[((long long)blockIdx.x * 4 + wave) * 6 + k] = ph[k];
+#endif
 
     if constexpr (STATS) {
         // one row per wave: sums over the 16 pixel lanes of each 16-lane row, written by its first lane
@@ -196,7 +219,7 @@ __global__ __launch_bounds__(256, KS == 1 ? 3 : 2) void first_conv_kernel(const 
 }
 
 // ---------------------------------------------------------------------------
-struct FcPlan { int tiles_x, tiles_y, ntiles, nwg, tiles_per_wg; };
+struct FcPlan { int tiles_x, tiles_y, ntiles, nwg, tiles_per_wg, walk; };
 
 static bool fc_plan(int N, int C, int H, int W, int Cout, FcPlan& p) {
     const char* e = getenv("FEA_AMD_FIRST_P");              // A/B switch: 0 = the one-tile-per-workgroup kernel of igemm.hip
@@ -209,6 +232,10 @@ static bool fc_plan(int N, int C, int H, int W, int Cout, FcPlan& p) {
     if (want > p.ntiles) want = p.ntiles;
     p.tiles_per_wg = (p.ntiles + want - 1) / want;
     p.nwg = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+    // interleaved walk when the stride (= the grid) is a whole number of tile columns; FEA_AMD_FIRST_WALK=0: consecutive (A/B runs)
+    static const bool nowalk = getenv("FEA_AMD_FIRST_WALK") && getenv("FEA_AMD_FIRST_WALK")[0] == '0';
+    p.walk = !nowalk && want % p.tiles_y == 0 && p.tiles_per_wg > 1;
+    if (p.walk) p.nwg = want;
     return true;
 }
 
@@ -228,6 +255,10 @@ bool fea_first_conv_p(const float* x, const void* w, const float* bias, void* y,
     a.x = x; a.w = (const __bf16*)w; a.bias = bias; a.y = (__bf16*)y; a.stats = stats;
     a.ldy = ldy; a.C = C; a.H = H; a.W = W;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_wg = p.tiles_per_wg;
+    a.walk = p.walk; a.wsx = (p.nwg / p.tiles_y) % p.tiles_x; a.wsn = p.nwg / (p.tiles_y * p.tiles_x);
+#ifdef FC_STAMPS
+    a.dbg = getenv("FC_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FC_DBG_PTR"), nullptr, 0) : nullptr;
+#endif
     dim3 grid((unsigned)p.nwg), block(256);
     const bool k1 = 9 * C <= 32;
 #define FC_LAUNCH(KSV, STV, RV) hipLaunchKernelGGL((first_conv_kernel<KSV, STV, RV>), grid, block, 0, s, a)

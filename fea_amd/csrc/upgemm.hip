@@ -39,7 +39,7 @@ struct UpgArgs {
     int Ntot, ntn;            // GEMM N, Ntot / 256
     int Cup;                  // channels per output quadrant
     int W;                    // input image width (power of two >= 16)
-    int tiles_per_walk;
+    int tiles_per_walk, tstride;
     unsigned long long* dbg;  // U_STAMPS builds only: shader cycles of every workgroup
 };
 
@@ -84,9 +84,12 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
     const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
     const int nt = slot % g.ntn;
     const int walk = (slot / g.ntn) * 8 + xcd;
-    const int t0 = walk * g.tiles_per_walk;
-    const int t1 = min(t0 + g.tiles_per_walk, g.ntiles);
-    if (t0 >= t1) return;
+    // tile walk: tstride == 1: tiles walk * tiles_per_walk ..., consecutive; tstride == number of walkers: tiles walk, walk + tstride,
+    // ... (at any moment the chip writes one compact window of output; conv_p.hip, scripts/hbm_tile_probe.hip).  t1 bounds the cursor.
+    const int tstride = g.tstride;
+    const int t0 = tstride == 1 ? walk * g.tiles_per_walk : walk;
+    if (t0 >= g.ntiles) return;
+    const int t1 = tstride == 1 ? min(t0 + g.tiles_per_walk, g.ntiles) : t0 + (g.ntiles - t0 + tstride - 1) / tstride * tstride;
     const int NC = g.NC;
 #ifdef U_STAMPS
     const unsigned long long tstart = __builtin_amdgcn_s_memtime();
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
 #ifdef U_EXP_HOT_DMA      // EXPERIMENT (wrong results): every chunk re-reads the first 64 KB = issue + LDS-write cost without the memory system
         psoA = 0; psoB = 0;
 #endif
-        if (++pc == NC) { pc = 0; ++ptile; }
+        if (++pc == NC) { pc = 0; ptile += tstride; }
     };
     auto produce_piece = [&](auto stc, auto ic) {
         constexpr int STG = decltype(stc)::value, i = decltype(ic)::value;
@@ -154,10 +157,10 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
     char* const dump = smem + 4 * U_REG + 1024;
     auto prefetch = [&](int tile, int it) {
 #if U_PREFETCH
-        const bool live = tile + 1 < t1 && g.ntn > 1;
+        const bool live = tile + tstride < t1 && g.ntn > 1;
         int pcr = rot + (it >> 2); if (pcr >= NC) pcr -= NC;
         int so;
-        so = (int)((unsigned)(tile + 1) * 256u * (unsigned)g.lda * 2u) + pcr * 128;
+        so = (int)((unsigned)(tile + tstride) * 256u * (unsigned)g.lda * 2u) + pcr * 128;
         upg_piece<0>(g.a, live ? g.a_bytes : 0u, dump, voffA, so + dA[it & 3]);
 #endif
     };
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void upg_kernel(const UpgArgs g) {
     sfor<0, 8>([&](auto mc) { rdA(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, mc); });
 
     const int npairs = NC >> 1;
-    for (int tile = t0; tile < t1; ++tile) {
+    for (int tile = t0; tile < t1; tile += tstride) {
         chunk_pair(std::true_type{}, tile != t0, tile, 0);
         for (int gi = 1; gi < npairs; ++gi) chunk_pair(std::false_type{}, false, tile, 2 * gi);
         epilogue(tile);
@@ -342,6 +345,9 @@ bool fea_upg_fwd(const void* x, int ldx, const void* w, const float* bias, void*
     if (nwalk < 8) nwalk = 8;
     a.tiles_per_walk = (a.ntiles + nwalk - 1) / nwalk;
     nwalk = ((a.ntiles + a.tiles_per_walk - 1) / a.tiles_per_walk + 7) / 8 * 8;
+    // interleaved walk (FEA_AMD_UPG_WALK=0: consecutive tiles, A/B runs)
+    static const bool consecutive = getenv("FEA_AMD_UPG_WALK") && getenv("FEA_AMD_UPG_WALK")[0] == '0';
+    a.tstride = consecutive || a.tiles_per_walk == 1 ? 1 : nwalk;
 #ifdef U_STAMPS
     a.dbg = getenv("UPG_DBG_PTR") ? (unsigned long long*)strtoull(getenv("UPG_DBG_PTR"), nullptr, 0) : nullptr;
 #endif

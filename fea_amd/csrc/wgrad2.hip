@@ -34,6 +34,7 @@ struct Wgrad2Args {
     int M, Nn;
     int tiles_x, tiles_y, ntiles, tiles_per_split;
     int nmt, nnt;
+    int wstride, wsx, wsy, wsn;   // wgrad4_kernel: split s takes tiles s * tiles_per_split ... (wstride 1) or s, s + wstride, ...; (wsx, wsy, wsn) = the stride in (x, y, image)
     unsigned long long* dbg;      // WG2_STAMPS builds only: per-wave phase cycle sums [workgroup][wave][6]
 };
 
@@ -711,8 +712,9 @@ __device__ __forceinline__ void wg4_kstep(Wg4Frag& cur, Wg4Frag& nxt, const uint
 
 template <int G, bool FAST>
 __device__ __forceinline__ void wg4_run(const Wgrad2Args& g, const __bf16* pg, const __bf16* qg,
-                                        const int (&pdesc)[4], const int (&qdesc)[6], unsigned qfl, int wave, int t_begin, int t_end,
+                                        const int (&pdesc)[4], const int (&qdesc)[6], unsigned qfl, int wave, int first, int t_begin, int t_end,
                                         char* smem, uint32_t (&pa)[4][2], uint32_t (&qa)[2][2][3], int h) {
+    // (t_begin .. t_end count this workgroup's own tiles; `first` is the tile the count starts at, the cursor advances by the walk's stride)
     constexpr int STAGE = (256 + 352) * 128;
     f32x4 acc[3][4][2];
 #pragma unroll
@@ -721,13 +723,15 @@ __device__ __forceinline__ void wg4_run(const Wgrad2Args& g, const __bf16* pg, c
         for (int i = 0; i < 8; ++i) acc[t][i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
     int ntx, nty, nn;
     {
-        int tt = t_begin;
+        int tt = first;
         ntx = tt % g.tiles_x; tt /= g.tiles_x;
         nty = tt % g.tiles_y; nn = tt / g.tiles_y;
     }
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int stage = (tile - t_begin) & 1;
-        if (++ntx == g.tiles_x) { ntx = 0; if (++nty == g.tiles_y) { nty = 0; ++nn; } }
+        ntx += g.wsx; if (ntx >= g.tiles_x) { ntx -= g.tiles_x; ++nty; }
+        nty += g.wsy; if (nty >= g.tiles_y) { nty -= g.tiles_y; ++nn; }
+        nn += g.wsn;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef WG4_EXP_NO_BARRIER       // EXPERIMENT (racy): no per-tile barrier
         __syncthreads();                 // this wave's LDS-DMA has landed; barrier: tile complete, other stage free
@@ -852,19 +856,22 @@ __global__ __launch_bounds__(512, 2) void wgrad4_kernel(const Wgrad2Args g) {
 
     const __bf16* __restrict__ pg = g.p + m0;
     const __bf16* __restrict__ qg = g.q + n0;
-    const int t_begin = split * g.tiles_per_split;
-    const int t_end = min(t_begin + g.tiles_per_split, g.ntiles);
+    // tile walk: consecutive tiles of a split (wstride 1), or every wstride-th tile: the chip then reads one compact window of
+    // wstride tiles at any moment (the 512 x 512 layers are HBM-bound; conv_p.hip's WALK)
+    const int first = g.wstride == 1 ? split * g.tiles_per_split : split;
+    const int t_begin = 0;
+    const int t_end = first >= g.ntiles ? 0 : g.wstride == 1 ? min(g.tiles_per_split, g.ntiles - first) : (g.ntiles - first + g.wstride - 1) / g.wstride;
 
     if (t_begin < t_end) {
-        int tt = t_begin;
+        int tt = first;
         const int tx = tt % g.tiles_x; tt /= g.tiles_x;
         wg2_issue<5, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, tx, tt % g.tiles_y, tt / g.tiles_y, smem);
     }
     if (WG2_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(WG2_PRIO);
-    if (grp == 0)      wg4_run<0, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, t_begin, t_end, smem, pa, qa, h);
-    else if (grp == 1) wg4_run<1, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, t_begin, t_end, smem, pa, qa, h);
-    else if (grp == 2) wg4_run<2, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, t_begin, t_end, smem, pa, qa, h);
-    else               wg4_run<3, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, t_begin, t_end, smem, pa, qa, h);
+    if (grp == 0)      wg4_run<0, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, first, t_begin, t_end, smem, pa, qa, h);
+    else if (grp == 1) wg4_run<1, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, first, t_begin, t_end, smem, pa, qa, h);
+    else if (grp == 2) wg4_run<2, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, first, t_begin, t_end, smem, pa, qa, h);
+    else               wg4_run<3, FAST>(g, pg, qg, pdesc, qdesc, qfl, wave, first, t_begin, t_end, smem, pa, qa, h);
     const float* ot = reinterpret_cast<const float*>(smem);
     float* dst = g.out + (long long)split * g.out_split_stride + ((long long)m0 * g.Nn + n0) * 9;
     for (int i = tid; i < 64 * 144; i += 512) {
@@ -914,6 +921,12 @@ int fea_wgrad2_launch(const void* dy, int lddy, const void* x, int ldx, float* d
     a.ldp = lddy; a.ldq = ldx; a.H = H; a.W = W; a.M = M; a.Nn = Nn;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
     a.nmt = p.nmt; a.nnt = p.nnt;
+    // wgrad4_kernel's tile walk: consecutive tiles per split.  FEA_AMD_WG_WALK=1 interleaves them (split s: tiles s, s + splits, ...):
+    // what gave the HBM-bound STORE streams of conv_p.hip 10 % does nothing for this kernel's reads (72.69 / 73.05 / 73.14 ms per step
+    // consecutive, 72.82 / 73.08 / 73.04 interleaved, same box).
+    static const bool inter = getenv("FEA_AMD_WG_WALK") && getenv("FEA_AMD_WG_WALK")[0] == '1';
+    a.wstride = !inter || p.tiles_per_split == 1 ? 1 : p.splits;
+    a.wsx = a.wstride % p.tiles_x; a.wsy = (a.wstride / p.tiles_x) % p.tiles_y; a.wsn = a.wstride / (p.tiles_x * p.tiles_y);
 #ifdef WG2_STAMPS
     a.dbg = getenv("WG2_DBG_PTR") ? (unsigned long long*)strtoull(getenv("WG2_DBG_PTR"), nullptr, 0) : nullptr;
 #endif

@@ -35,9 +35,14 @@ __global__ __launch_bounds__(256) void tile_fill_k(const TArgs g) {
             for (int u = wave; u < units; u += 4) {
                 // half 1: four consecutive lanes write one pixel's 64 bytes; half 2: the direct-store epilogue's lanes (conv_p.hip,
                 // first_conv.hip): consecutive lanes are consecutive PIXELS, the four 16-byte pieces of a half sit 16 lanes apart
-                char* p = base + (u / upr) * g.pitch + (u % upr) * 2048 +
-                          (g.half == 1 ? (lane >> 2) * 128 + (lane & 3) * 16 : (lane & 15) * 128 + (lane >> 4) * 16);
-                put(p); put(p + 64);
+                char* p = base + (u / upr) * g.pitch + (u % upr) * 2048;
+                if (g.half == 1)      { p += (lane >> 2) * 128 + (lane & 3) * 16; put(p); put(p + 64); }
+                else if (g.half == 2) { p += (lane & 15) * 128 + (lane >> 4) * 16; put(p); put(p + 64); }
+                else {
+                    // half 3: each instruction covers 8 whole pixels (1 KB contiguous), lanes permuted as a row_ror:8 exchange of the
+                    // direct-store epilogue's two halves would leave them: lane (r16, q) -> pixel r16 & 7, half r16 >> 3, chunk q
+                    p += (lane & 7) * 128 + ((lane >> 3) & 1) * 64 + (lane >> 4) * 16; put(p); put(p + 1024);
+                }
             }
         }
     }
@@ -48,11 +53,11 @@ int main() {
     char* a; CK(hipMalloc(&a, bytes)); CK(hipMemset(a, 1, bytes));
     int* bad; CK(hipMalloc(&bad, 4)); CK(hipMemset(bad, 0, 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int shapes[][2] = {{8, 4096}, {1, 32768}};
+    const int shapes[][2] = {{8, 4096}};
     for (auto& sh : shapes)
-        for (int nwg : {512, 768})
+        for (int nwg : {768})
             for (int chunked = 0; chunked < 2; ++chunked)
-                for (int half = 0; half < 3; ++half)
+                for (int half = 0; half < 4; ++half)
                     for (int xcd = 0; xcd < 2; ++xcd) {
                         if (xcd && !chunked) continue;
                         TArgs g{a, sh[0], sh[1], (int)(pitch / sh[1]), 512 / sh[0], 0, chunked, half, xcd, pitch, img, bytes, bad};
@@ -64,8 +69,8 @@ int main() {
                         for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(tile_fill_k, dim3(nwg), dim3(256), 0, 0, g);
                         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
-                        printf("tile %2d x %5d B  nwg %4d  %-11s %-9s %-4s %7.3f ms  %5.2f TB/s\n", sh[0], sh[1], nwg,
-                               chunked ? "chunked" : "interleaved", half == 2 ? "16B-lanes" : half ? "64B-halves" : "1KB", xcd ? "xcd" : "", ms, bytes / ms / 1e9);
+                        printf("tile %2d x %5d B  nwg %4d  %-11s %-12s %-4s %7.3f ms  %5.2f TB/s\n", sh[0], sh[1], nwg,
+                               chunked ? "chunked" : "interleaved", half == 3 ? "1KB-permuted" : half == 2 ? "16B-lanes" : half ? "64B-halves" : "1KB", xcd ? "xcd" : "", ms, bytes / ms / 1e9);
                     }
     int hb = 0; CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost));
     printf("out-of-range stores suppressed: %s\n", hb ? "YES (index bug)" : "none");
