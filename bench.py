@@ -163,7 +163,7 @@ def spawn_ranks(a, argv):
     tree via torch.distributed.run, before this process has made any HIP / torch.cuda call (a process that has touched
     the GPU must never be re-exec'd), relay the child's output (rank 0's JSON line) and return its exit code."""
     have = torch.cuda.device_count()            # counting devices does not initialise the GPU
-    if have < a.gpus:
+    if have < a.gpus and os.environ.get("FEA_BENCH_SHARE_GPU") != "1":
         print(f"bench.py: --gpus {a.gpus} requested but this node exposes {have} GPU(s); not running a smaller job "
               "under the same label", file=sys.stderr)
         return 2
@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
 
+    if os.environ.get("FEA_BENCH_DUMP_AFTER"):     # debugging aid: Python stacks of every thread to stderr after S seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["FEA_BENCH_DUMP_AFTER"]), exit=True)
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not launched and a.gpus > 1:
         sys.exit(spawn_ranks(a, sys.argv[1:]))
@@ -202,9 +205,19 @@ def main():
         sys.exit(2)
     # FEA_BENCH_FORCE_DIST=1: take the RCCL / bucketed all-reduce path even with one rank (rehearsal)
     distributed = world > 1 or (os.environ.get("FEA_BENCH_FORCE_DIST") == "1" and launched)
+    # FEA_BENCH_BACKEND=gloo + FEA_BENCH_SHARE_GPU=1: rehearsal of the N-rank path on a box with fewer GPUs than ranks
+    # (RCCL refuses two ranks on one device; gloo reduces device tensors through the host).  Never a scaling number:
+    # the JSON line says so in config.parallelism.
+    backend = os.environ.get("FEA_BENCH_BACKEND", "nccl")
+    share = os.environ.get("FEA_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if distributed:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         world = dist.get_world_size()          # n_gpus in the JSON line is what RCCL reports
 
     import fea_amd
@@ -235,10 +248,11 @@ def main():
     dt = time.perf_counter() - t0
     per_rank = [a.batch * a.steps / dt_own]
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        sdev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=sdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        mine = torch.tensor([per_rank[0]], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([per_rank[0]], dtype=torch.float64, device=sdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [float(v.item()) for v in allr]
@@ -274,7 +288,8 @@ def main():
                                    f"{a.dtype} storage / fp32 accumulate, BCE+Dice loss, clip 1.0, AdamW"
                                    + (f" (BASELINE configs[2]{'/[3]' if world > 1 else ''})" if (a.batch, a.size, a.dtype) == (64, 512, "bf16")
                                       else (" (BASELINE configs[1])" if (a.batch, a.size, a.dtype) == (16, 256, "fp32") else "")),
-                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "per_gpu_batch": a.batch},
+                       "global_batch": world * a.batch, "per_gpu_batch": a.batch,
+                       "parallelism": f"dp{world}" + (f" (REHEARSAL: {backend}, ranks share GPUs)" if (share or backend != "nccl") and distributed else "")},
             "per_rank_images_per_s": per_rank,
             "whole_step_tflops_per_gpu": ips / world * gf / 1e3,
             "whole_step_mfma_frac": ips / world * gf / 1e3 / (PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS),

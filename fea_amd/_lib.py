@@ -13,6 +13,8 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_v
 
 import torch
 
+from . import trace
+
 F32, BF16 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FEA_AMD_LIB") or os.path.join(_HERE, "libfea_unet.so")   # env override: A/B builds in scripts/
@@ -158,6 +160,10 @@ def call(name: str, *args):
         rc = fn(*conv)
         e1.record()
         PROFILE.append((name, e0, e1, conv))
+    elif trace.CALLS:
+        trace.push(name)
+        rc = fn(*conv)
+        trace.pop()
     else:
         rc = fn(*conv)
     if SIGNATURES[name][0] is I and rc < 0 and not name.endswith(("_blocks", "_tiles", "_chunk", "_ksize", "_coeffs", "_rows", "_supported")):

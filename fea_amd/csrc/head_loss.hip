@@ -321,11 +321,12 @@ __global__ __launch_bounds__(256) void mask_iou_kernel(const float* __restrict__
     unsigned ni = 0, nu = 0;
     for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
         const bool pr = x[b + i] > 0.f;
-        const bool tg = t[b + i] != 0;
+        const bool tg = t ? t[b + i] != 0 : false;          // no target: the mask alone (inference without ground truth)
         if (mask) mask[b + i] = pr ? 1 : 0;
         ni += (pr && tg) ? 1u : 0u;
         nu += (pr || tg) ? 1u : 0u;
     }
+    if (!t) return;                                         // block-uniform: no barrier is skipped by part of a block
     __shared__ unsigned sh[4][2];
     for (int o = 32; o > 0; o >>= 1) { ni += __shfl_down(ni, o); nu += __shfl_down(nu, o); }
     if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = ni; sh[threadIdx.x >> 6][1] = nu; }
@@ -1184,7 +1185,8 @@ extern "C" int fea_bce_dice_grad(const float* logits, const uint8_t* target, con
 
 extern "C" int fea_mask_iou(const float* logits, const uint8_t* target, uint8_t* mask, long long* inter, long long* uni,
                             int N, int Ccls, long long HW, void* stream) {
-    FEA_CHECK(logits && target && inter && uni && N > 0 && Ccls > 0 && HW > 0, FEA_E_BADARG, "fea_mask_iou: bad args");
+    // target == NULL: threshold only (mask required, the counts are left alone and may be NULL)
+    FEA_CHECK(logits && (target ? (inter && uni) : mask != nullptr) && N > 0 && Ccls > 0 && HW > 0, FEA_E_BADARG, "fea_mask_iou: bad args");
     int chunks; long long cl; loss_plan(HW, chunks, cl);
     hipLaunchKernelGGL(mask_iou_kernel, dim3(N * Ccls * chunks), dim3(256), 0, (hipStream_t)stream, logits, target, mask,
                        (unsigned long long*)inter, (unsigned long long*)uni, HW, Ccls, chunks, cl);

@@ -32,6 +32,7 @@ from typing import Callable, Dict, List, Optional
 import torch
 
 from . import _lib as L
+from . import trace
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -460,6 +461,7 @@ class UNetEngine:
         return self._pack(name + ("/b" if bwd else "/f"), p, p.numel(), "fea_pack_upconv2x2", ci, co, bwd)
 
     # -------------------------------------------------------------- forward
+    @trace.traced("unet.forward")
     def forward(self, x: torch.Tensor, training: bool, head: bool = True) -> Optional[torch.Tensor]:
         """`head=False` (training loops that use the fused head + loss kernels, see backward(target=...)): stop after
         dec1; the logits are formed inside the loss kernels and never stored."""
@@ -626,6 +628,7 @@ class UNetEngine:
     def fused_loss_supported(self, H: int, W: int) -> bool:
         return bool(L.call("fea_head_loss_supported", H, W, self.num_classes))
 
+    @trace.traced("unet.backward")
     def backward(self, dlogits: Optional[torch.Tensor], plan: Optional[_Plan] = None,
                  target: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Gradients of every parameter for upstream gradient `dlogits`

@@ -86,6 +86,15 @@ def mask_iou_counts(logits: torch.Tensor, target_u8: torch.Tensor, want_mask: bo
     return mask, inter, union
 
 
+def threshold_mask(logits: torch.Tensor) -> torch.Tensor:
+    """pred = logits > 0 as uint8 {0,1} (inference.py:39-40 without ground truth): fea_mask_iou with no target."""
+    n, c, h, w = logits.shape
+    lg = logits.detach().contiguous().float()
+    mask = torch.empty((n, c, h, w), dtype=torch.uint8, device=lg.device)
+    L.call("fea_mask_iou", lg, None, mask, None, None, n, c, h * w, L.stream_ptr())
+    return mask
+
+
 def iou_from_counts(inter: torch.Tensor, union: torch.Tensor):
     iou = torch.where(union > 0, inter.double() / union.clamp(min=1).double(), torch.ones_like(inter, dtype=torch.float64))
     return iou, iou.mean()

@@ -103,7 +103,7 @@ class TiledSegmenter:
         summed over ranks (one int64 all-reduce: the path's only exchange step)."""
         lg = self.logits(x)
         if target_u8 is None:
-            return (lg > 0).to(torch.uint8), None, None
+            return Fn.threshold_mask(lg), None, None
         mask, inter, union = Fn.mask_iou_counts(lg, target_u8, want_mask=True)
         inter, union = reduce_counts(inter, union, group)
         return mask, inter, union

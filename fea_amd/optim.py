@@ -22,6 +22,7 @@ from typing import Iterable, Tuple
 import torch
 
 from . import _lib as L
+from . import trace
 
 
 class ClipAdamW(torch.optim.Optimizer):
@@ -87,6 +88,7 @@ class ClipAdamW(torch.optim.Optimizer):
 
     # --------------------------------------------------------------------- step
     @torch.no_grad()
+    @trace.traced("clip+adamw.step")
     def step(self, closure=None):
         """One clipped AdamW step on the gradients currently in the engine's flat buffer.
         Returns the (unclipped) total gradient norm as a 1-element device tensor."""

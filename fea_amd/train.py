@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from . import trace
 from . import functional as Fn
 from .engine import param_order
 from .optim import ClipAdamW
@@ -51,15 +52,23 @@ class GradBuckets:
             self.buckets.append((start, cur_end, order[-1]))
         self.trigger = {last: i for i, (_, _, last) in enumerate(self.buckets)}
         self.on_gpu = engine.flat_grad.is_cuda
+        self.has_avg = dist.get_backend(group) == "nccl"      # RCCL; gloo (CPU tests, one-GPU rehearsals) has no AVG
         self.stream = torch.cuda.Stream() if self.on_gpu else None
         self.pending = []
         engine.grad_ready = self.on_ready
 
+    @trace.traced("grad.bucket_allreduce")
     def _reduce(self, s, e):
         sl = self.eng.flat_grad[s:e]
-        if self.on_gpu:
+        if self.has_avg:
             # RCCL averages inside the collective: no second pass over the bucket on the communication stream
             dist.all_reduce(sl, op=dist.ReduceOp.AVG, group=self.group)
+        elif self.on_gpu:
+            # gloo with device gradients (rehearsal of the N-rank path on a box with fewer GPUs than ranks; its
+            # device-tensor all-reduce hangs on this ROCm build): through the host, on the communication stream
+            h = sl.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            sl.copy_(h.mul_(1.0 / self.world))
         else:                                    # gloo has no AVG
             dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
             sl.mul_(1.0 / self.world)
@@ -147,6 +156,7 @@ class UNetTrainer:
         re-assignment of p.grad: the step would then run forward and backward and update nothing."""
         return all(p.grad is not None and p.grad.data_ptr() == ptr for p, ptr in self._bound)
 
+    @trace.traced("train.step")
     def step(self, x: torch.Tensor, target_u8: torch.Tensor):
         """One optimisation step; returns the loss as a 1-element device tensor."""
         m = self.model

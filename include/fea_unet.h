@@ -280,7 +280,9 @@ int fea_bce_dice_sums_static(const float* logits, const uint8_t* target, double*
 /* loss[0] = BCE(mean) + 1 - mean_c dice_c ; dlogits = d loss / d logits * gscale */
 int fea_bce_dice_grad(const float* logits, const uint8_t* target, const double* sums, float* loss, float* dlogits,
                       float gscale, int N, int Ccls, long long HW, void* stream);
-/* mask = logits > 0 (nullable out); inter/union int64[Ccls] are ACCUMULATED (caller zeroes). */
+/* mask = logits > 0 (nullable out); inter/union int64[Ccls] are ACCUMULATED (caller zeroes).
+   target == NULL: threshold only (inference without ground truth, inference.py:39-40): mask is required, inter/uni
+   are not touched and may be NULL. */
 int fea_mask_iou(const float* logits, const uint8_t* target, uint8_t* mask, long long* inter, long long* uni,
                  int N, int Ccls, long long HW, void* stream);
 /* Head + loss fused for training loops: the logits and their gradient stay in registers.

@@ -456,6 +456,10 @@ def test_tiled_inference_equals_whole_image(dt):
     # IoU counts are exact for the logits they are computed from
     _, ref_i, ref_u = O.mask_iou_counts(tiled.cpu(), tgt.cpu())
     assert torch.equal(it.cpu(), ref_i) and torch.equal(ut.cpu(), ref_u)
+    # without ground truth: the same mask through the same kernel (no target, no counts)
+    mask_n, i_n, u_n = seg.segment(x)
+    assert i_n is None and u_n is None and mask_n.dtype == torch.uint8
+    assert torch.equal(mask_n, mask_t) and torch.equal(mask_n.cpu(), (tiled > 0).to(torch.uint8).cpu())
 
 
 def test_hip_optimizer_matches_torch_adamw_and_shares_checkpoints():
