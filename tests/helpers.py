@@ -43,3 +43,36 @@ def digest_err(gold: dict, t: torch.Tensor) -> float:
     scale = max(gs.abs().max().item(), gold["l2"] / max(gold["n"], 1) ** 0.5, 1e-30)
     errs.append(((gs - ds).abs().max() / scale).item())
     return max(errs)
+
+
+DENSE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "unet_dense.npz")
+
+
+def load_dense():
+    """tests/golden/unet_dense.npz (oracle/make_golden_dense.py): FULL reference tensors of case train_32."""
+    import numpy as np
+    z = np.load(DENSE, allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return z, meta
+
+
+def dense_take(t: torch.Tensor, meta: dict) -> torch.Tensor:
+    """The element set oracle/make_golden_dense.py:element_set keeps of a tensor: every element up to meta['whole'],
+    else the first meta['head'] elements plus meta['head'] evenly strided ones."""
+    f = t.detach().reshape(-1).float().cpu()
+    n = f.numel()
+    if n <= meta["whole"]:
+        return f
+    head = meta["head"]
+    idx = torch.unique(torch.cat([torch.arange(head), torch.arange(head) * (n // head)]))
+    return f[idx]
+
+
+def dense_err(got: torch.Tensor, ref) -> float:
+    """max |got - ref| over the kept elements / RMS of ref (element-by-element: no digest, no norm ratio that a
+    few wrong elements could hide in)."""
+    r = torch.as_tensor(ref).double().flatten()
+    g = got.double().flatten()
+    assert g.numel() == r.numel(), (g.numel(), r.numel())
+    rms = r.pow(2).mean().sqrt().item()
+    return ((g - r).abs().max().item()) / max(rms, 1e-30)

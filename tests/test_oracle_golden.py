@@ -171,3 +171,37 @@ def test_config1_on_a_real_floor_plan_matches_the_reference():
         y, _ = O.forward(params, bufs, x, training=False)
     assert digest_err(rec["logits"], y) < TOL
     assert abs(int((y > 0).sum()) - rec["pred_sum"]) <= 4
+
+
+def test_oracle_against_reference_dense_tensors():
+    """Element by element, not through digests: the oracle against the reference's FULL logits, gradients (whole
+    tensors up to 65,536 elements, 8,192 elements of each larger one), BatchNorm buffers, post-AdamW parameters and
+    eval logits of case train_32 (tests/golden/unet_dense.npz, written by oracle/make_golden_dense.py from the
+    reference module).  Bound: max element error <= 1e-4 of the tensor's RMS (train_32 is a well-conditioned seed: no
+    ReLU / pool decision within rounding of its kink)."""
+    from tests.helpers import dense_err, dense_take, load_dense
+    z, meta = load_dense()
+    case = GOLD["train_32"]
+    assert (meta["seed"], meta["n"], meta["h"], meta["w"]) == (case["seed"], case["n"], case["h"], case["w"])
+    torch.set_num_threads(8)
+    params, bufs = O.split_state(_case_state(case))
+    x, tgt = case_inputs(case)
+    loss, logits, grads, nb = O.loss_and_grads(params, bufs, x, tgt, training=True)
+    assert abs(float(loss) - float(z["loss"])) <= 1e-6 * abs(float(z["loss"]))
+    assert dense_err(logits, z["logits"]) < 1e-5
+    worst = max((dense_err(dense_take(g, meta), z["grad/" + k]), k) for k, g in grads.items() if not _bn_cancelled_bias(k))
+    assert worst[0] < 1e-4, worst
+    for k, b in nb.items():
+        if not k.endswith("num_batches_tracked"):
+            assert dense_err(dense_take(b, meta), z["buffer/" + k]) < 1e-5, k
+    clipped, _ = O.clip_grad_norm(grads, 1.0)
+    after = O.adamw_step(params, clipped, {})
+    for k, p in after.items():
+        if not _bn_cancelled_bias(k):
+            ref = torch.as_tensor(z["after/" + k]).double()
+            # an Adam step moves an element by <= lr; elements whose gradient is ~eps are sign-like: absolute bound
+            assert (dense_take(p, meta).double() - ref).abs().max().item() <= 1e-6 * ref.abs().max().item() + 0.1 * 1e-4, k
+    le, _ = O.forward(after, nb, x, training=False)
+    # eval mode uses the running statistics, so the +-lr sign-like moves of the BatchNorm-cancelled conv biases (noise
+    # gradients) no longer cancel: same 5e-4 as the digest test above
+    assert dense_err(le, z["eval_logits"]) < 5e-4
