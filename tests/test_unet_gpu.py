@@ -74,7 +74,7 @@ def run_hip(m, x, dl):
     return lg.detach().cpu(), {k: v.cpu() for k, v in taps.items()}
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 32), (1, 64, 48), (3, 16, 16), (1, 128, 96)])
+@pytest.mark.parametrize("shape", [(2, 32, 32), (1, 64, 48), (3, 16, 16), (1, 128, 96), (5, 48, 80), (1, 16, 144), (2, 176, 16)])
 def test_fp32_forward_backward_buffers(shape):
     n, h, w = shape
     m, params, bufs = make(10, "fp32")
@@ -111,7 +111,7 @@ def test_fp32_forward_backward_buffers(shape):
     assert rel_l2(le, lo_e) < 1e-4 and max_rel(le, lo_e) < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 32), (4, 64, 64), (2, 256, 192)])
+@pytest.mark.parametrize("shape", [(2, 32, 32), (4, 64, 64), (2, 256, 192), (3, 48, 80), (1, 16, 272), (5, 80, 16), (1, 144, 112)])
 def test_bf16_forward_backward(shape):
     n, h, w = shape
     m, params, bufs = make(11, "bf16")
