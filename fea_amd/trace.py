@@ -37,7 +37,7 @@ def pop():
 
 
 @contextlib.contextmanager
-def range(name: str):          # noqa: A001 (the roctx term)
+def span(name: str):
     push(name)
     try:
         yield

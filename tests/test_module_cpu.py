@@ -86,3 +86,19 @@ def test_product_synthetic_batch_is_the_oracles():
     a, ta = synthetic_batch(2, 48, 32, seed=77)
     b, tb = O.synthetic_batch(2, 48, 32, seed=77)
     assert torch.equal(a, b) and torch.equal(ta, tb)
+
+
+def test_trace_is_free_when_off(monkeypatch):
+    """fea_amd.trace (roctx ranges): with FEA_AMD_ROCTX unset the decorator returns the function it was given and no
+    marker library is loaded."""
+    import importlib
+    monkeypatch.delenv("FEA_AMD_ROCTX", raising=False)
+    from fea_amd import trace
+    trace = importlib.reload(trace)
+    assert trace.LEVEL == 0 and not trace.CALLS
+
+    def f(x):
+        return x + 1
+    assert trace.traced("anything")(f) is f
+    with trace.span("nothing happens"):
+        assert f(1) == 2
