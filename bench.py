@@ -231,7 +231,7 @@ def main():
     # four different batches per rank, resident in HBM before the timed region, taken in turn (a step never sees the
     # batch of the step before it)
     batches = []
-    for i in range(4):
+    for i in range(1 if os.environ.get("FEA_BENCH_ONE_BATCH") == "1" else 4):      # (A/B switch: one reused batch)
         bx, bt = synthetic_batch(a.batch, a.size, a.size, seed=1234 + rank + 1000 * i)
         batches.append((bx.cuda(), bt.cuda()))
     x, tgt = batches[0]
@@ -242,11 +242,11 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
-        loss = trainer.step(*batches[i % 4])
+        loss = trainer.step(*batches[i % len(batches)])
     sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        loss = trainer.step(*batches[(a.warmup + i) % 4])
+        loss = trainer.step(*batches[(a.warmup + i) % len(batches)])
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0          # this rank alone (shows a straggler)
     sync()
@@ -293,7 +293,7 @@ def main():
                                    f"{a.dtype} storage / fp32 accumulate, BCE+Dice loss, clip 1.0, AdamW"
                                    + (f" (BASELINE configs[2]{'/[3]' if world > 1 else ''})" if (a.batch, a.size, a.dtype) == (64, 512, "bf16")
                                       else (" (BASELINE configs[1])" if (a.batch, a.size, a.dtype) == (16, 256, "fp32") else "")),
-                       "global_batch": world * a.batch, "per_gpu_batch": a.batch, "distinct_batches_per_rank": 4,
+                       "global_batch": world * a.batch, "per_gpu_batch": a.batch, "distinct_batches_per_rank": len(batches),
                        "parallelism": f"dp{world}" + (f" (REHEARSAL: {backend}, ranks share GPUs)" if (share or backend != "nccl") and distributed else "")},
             "per_rank_images_per_s": per_rank,
             "whole_step_tflops_per_gpu": ips / world * gf / 1e3,
