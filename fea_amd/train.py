@@ -52,7 +52,7 @@ class GradBuckets:
             self.buckets.append((start, cur_end, order[-1]))
         self.trigger = {last: i for i, (_, _, last) in enumerate(self.buckets)}
         self.on_gpu = engine.flat_grad.is_cuda
-        self.has_avg = dist.get_backend(group) == "nccl"      # RCCL; gloo (CPU tests, one-GPU rehearsals) has no AVG
+        self.has_avg = self.on_gpu and dist.get_backend(group) == "nccl"      # RCCL; gloo (CPU tests, one-GPU rehearsals) has no AVG
         self.stream = torch.cuda.Stream() if self.on_gpu else None
         self.pending = []
         engine.grad_ready = self.on_ready
