@@ -193,6 +193,8 @@ def main():
     if os.environ.get("FEA_BENCH_DUMP_AFTER"):     # debugging aid: Python stacks of every thread to stderr after S seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["FEA_BENCH_DUMP_AFTER"]), exit=True)
+    # the host driver of this pool only supports dmabuf IPC: RCCL needs this before the first HIP call of every rank
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not launched and a.gpus > 1:
         sys.exit(spawn_ranks(a, sys.argv[1:]))
